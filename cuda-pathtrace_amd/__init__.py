@@ -1,0 +1,279 @@
+"""cuda-pathtrace_amd -- MI355X (gfx950) implementation of cuda-pathtrace's per-pixel
+Monte-Carlo megakernel, behind the C ABI of include/ptcore.h.
+
+This Python module is only the ctypes view of libptcore.so used by tests/, bench.py and the
+multi-GPU driver (one process per GPU under torch.distributed).  The product is the shared
+library and the C++ look-alike headers in host/; nothing here computes pixels, and there is
+no CPU fallback: importing works without a GPU (the library loads), every compute call
+raises PtError when no HIP device is usable, and a missing libptcore.so raises at import.
+
+The directory name has a hyphen (it is fixed by the project layout), so import it through
+`load_package()` in __graft_entry__.py / tests/conftest.py, which registers it as
+`cuda_pathtrace_amd`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptcore.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C cuda-pathtrace_amd/csrc` "
+        "(or __graft_entry__.build()); there is no fallback implementation"
+    )
+
+RNG_XORWOW = 0
+RNG_PHILOX = 1
+CHANNELS = 14
+
+SPHERE_DTYPE = np.dtype([("radius", "<f4"), ("pos", "<f4", 3), ("emission", "<f4", 3), ("color", "<f4", 3)])
+assert SPHERE_DTYPE.itemsize == 40
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ptcore error {code}: {msg}")
+        self.code = code
+
+
+class RendererOpts(ctypes.Structure):
+    _fields_ = [
+        ("max_bounces", ctypes.c_int32),
+        ("rng_mode", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("row_begin", ctypes.c_int32),
+        ("row_end", ctypes.c_int32),
+        ("persist_rng", ctypes.c_int32),
+        ("variant", ctypes.c_int32),
+    ]
+
+
+class KernelInfo(ctypes.Structure):
+    _fields_ = [
+        ("block_threads", ctypes.c_int32),
+        ("grid_blocks", ctypes.c_int32),
+        ("lds_bytes", ctypes.c_int32),
+        ("num_vgprs", ctypes.c_int32),
+        ("num_sgprs", ctypes.c_int32),
+        ("scratch_bytes", ctypes.c_int32),
+        ("max_spheres", ctypes.c_int32),
+    ]
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); this table is also what tests check against include/ptcore.h
+ABI = {
+    "pt_abi_version": (ctypes.c_int, []),
+    "pt_last_error": (ctypes.c_char_p, []),
+    "pt_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "pt_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "pt_device_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "pt_malloc": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    "pt_free": (ctypes.c_int, [_vp]),
+    "pt_memcpy_h2d": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pt_memcpy_d2h": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pt_memset": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_size_t]),
+    "pt_device_synchronize": (ctypes.c_int, []),
+    "pt_renderer_opts_default": (None, [ctypes.POINTER(RendererOpts)]),
+    "pt_renderer_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RendererOpts), ctypes.POINTER(_vp)]),
+    "pt_renderer_destroy": (ctypes.c_int, [_vp]),
+    "pt_renderer_render": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _fp]),
+    "pt_renderer_enqueue": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _vp]),
+    "pt_renderer_set_frame": (ctypes.c_int, [_vp, ctypes.c_uint32]),
+    "pt_renderer_reset_rng": (ctypes.c_int, [_vp]),
+    "pt_renderer_get_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pt_renderer_set_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pt_renderer_kernel_info": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(KernelInfo)]),
+    "pt_scene_cornell": (ctypes.c_int, [_vp]),
+    "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
+    "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
+}
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in ABI.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export the ABI
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc):
+    if rc != 0:
+        raise PtError(rc, lib.pt_last_error().decode("utf-8", "replace"))
+
+
+def _f32(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(n)
+    return a, a.ctypes.data_as(_fp)
+
+
+# ---- host-side inputs -----------------------------------------------------------------
+def scene_cornell():
+    s = np.zeros(9, dtype=SPHERE_DTYPE)
+    check(lib.pt_scene_cornell(s.ctypes.data))
+    return s
+
+
+def scene_random(n, seed=0, with_walls=True):
+    s = np.zeros(n, dtype=SPHERE_DTYPE)
+    check(lib.pt_scene_random(n, seed, 1 if with_walls else 0, s.ctypes.data))
+    return s
+
+
+DEFAULT_EYE = (50.0, 52.0, 295.6)  # src/main.cu:24
+
+
+def camera_basis(pos=DEFAULT_EYE, yaw=-90.0, pitch=0.0, width=512, height=512):
+    p, pp = _f32(pos, 3)
+    out = np.zeros(12, dtype=np.float32)
+    check(lib.pt_camera_basis(pp, yaw, pitch, width, height, out.ctypes.data_as(_fp)))
+    return out
+
+
+# ---- device ---------------------------------------------------------------------------
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib.pt_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    check(lib.pt_set_device(i))
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int(0)
+    khz = ctypes.c_int(0)
+    check(lib.pt_device_info(name, 256, ctypes.byref(cus), ctypes.byref(khz)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "clock_khz": khz.value}
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes (OutputBuffer::AllocateGPU / Scene's sphere upload)."""
+
+    def __init__(self, nbytes):
+        p = _vp()
+        check(lib.pt_malloc(ctypes.byref(p), nbytes))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib.pt_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib.pt_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib.pt_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def upload_scene(spheres):
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    return DeviceBuffer(max(spheres.nbytes, 4)).upload(spheres), len(spheres)
+
+
+class Renderer:
+    """ctypes view of pt_renderer (the reference's class Renderer, include/Renderer.h)."""
+
+    def __init__(self, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
+                 row_begin=0, row_end=0, persist_rng=True, variant=0):
+        o = RendererOpts()
+        lib.pt_renderer_opts_default(ctypes.byref(o))
+        o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
+        o.row_begin, o.row_end = row_begin, row_end
+        o.persist_rng, o.variant = (1 if persist_rng else 0), variant
+        h = _vp()
+        check(lib.pt_renderer_create(width, height, spp, threads_per_block, ctypes.byref(o), ctypes.byref(h)))
+        self.handle = h.value
+        self.width, self.height, self.spp = width, height, spp
+        self.row_begin = row_begin
+        self.row_end = row_end if (row_begin or row_end) else height
+        self.rows = self.row_end - self.row_begin
+
+    @property
+    def tile_floats(self):
+        return self.rows * self.width * CHANNELS
+
+    def render(self, d_out, d_spheres, n_spheres, basis, eye=DEFAULT_EYE):
+        """Synchronous Render(); returns kernel milliseconds (Renderer.h:55-76)."""
+        _, b = _f32(basis, 12)
+        _, e = _f32(eye, 3)
+        ms = ctypes.c_float(0)
+        check(lib.pt_renderer_render(self.handle, d_out, d_spheres, n_spheres, b, e, ctypes.byref(ms)))
+        return ms.value
+
+    def enqueue(self, d_out, d_spheres, n_spheres, basis, eye=DEFAULT_EYE, stream=None):
+        _, b = _f32(basis, 12)
+        _, e = _f32(eye, 3)
+        check(lib.pt_renderer_enqueue(self.handle, d_out, d_spheres, n_spheres, b, e, stream))
+
+    def set_frame(self, frame):
+        check(lib.pt_renderer_set_frame(self.handle, frame))
+
+    def reset_rng(self):
+        check(lib.pt_renderer_reset_rng(self.handle))
+
+    def get_rng_state(self):
+        st = np.zeros((self.rows * self.width, 6), dtype=np.uint32)
+        check(lib.pt_renderer_get_rng_state(self.handle, st.ctypes.data, st.size))
+        return st
+
+    def set_rng_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.uint32)
+        check(lib.pt_renderer_set_rng_state(self.handle, st.ctypes.data, st.size))
+
+    def kernel_info(self, n_spheres):
+        ki = KernelInfo()
+        check(lib.pt_renderer_kernel_info(self.handle, n_spheres, ctypes.byref(ki)))
+        return {f: getattr(ki, f) for f, _ in KernelInfo._fields_}
+
+    def destroy(self):
+        if self.handle:
+            check(lib.pt_renderer_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def render_frame(width, height, spp, spheres=None, basis=None, eye=DEFAULT_EYE, **opts):
+    """Convenience for tests: allocate, render rows [row_begin,row_end) on the GPU, download.
+    Returns (float32 [rows][width][14], kernel_ms)."""
+    if spheres is None:
+        spheres = scene_cornell()
+    if basis is None:
+        basis = camera_basis(eye, width=width, height=height)
+    r = Renderer(width, height, spp, **opts)
+    d_scene, n = upload_scene(spheres)
+    d_out = DeviceBuffer(max(r.tile_floats * 4, 4))
+    try:
+        ms = r.render(d_out.ptr, d_scene.ptr, n, basis, eye)
+        img = d_out.download(np.float32, (r.rows, width, CHANNELS))
+    finally:
+        d_out.free()
+        d_scene.free()
+        r.destroy()
+    return img, ms

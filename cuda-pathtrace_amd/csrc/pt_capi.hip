@@ -1,0 +1,277 @@
+// pt_capi.hip -- the C ABI of include/ptcore.h on top of the HIP runtime.
+// Host code only; device code is in pt_kernel.hip.  No CPU fallback exists: every compute
+// entry point fails with PT_ENODEVICE / PT_EHIP when no gfx950 device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "pt_internal.h"
+#include "pt_kernel.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int pt_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define PT_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return pt_fail(e_ == hipErrorNoDevice ? PT_ENODEVICE : PT_EHIP, "%s: %s (%s:%d)", #call,    \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                                  \
+  } while (0)
+
+struct pt_renderer {
+  int width, height, spp, threads_per_block;
+  pt_renderer_opts opts;
+  uint32_t tile_pixels;
+  uint32_t frame;
+  uint32_t* d_state;  // xorwow persistent state (Renderer::d_states), or nullptr
+  hipEvent_t ev_start, ev_stop;
+  int device;
+};
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+const char* pt_last_error(void) { return g_err; }
+
+int pt_set_device(int device) {
+  PT_HIP(hipSetDevice(device));
+  return PT_OK;
+}
+
+int pt_device_count(int* count) {
+  if (!count) return pt_fail(PT_EINVAL, "pt_device_count: count is NULL");
+  *count = 0;
+  PT_HIP(hipGetDeviceCount(count));
+  return PT_OK;
+}
+
+int pt_device_info(char* name, size_t name_len, int* compute_units, int* clock_khz) {
+  int dev = 0;
+  PT_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  PT_HIP(hipGetDeviceProperties(&prop, dev));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  return PT_OK;
+}
+
+int pt_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return pt_fail(PT_EINVAL, "pt_malloc: d_ptr is NULL");
+  PT_HIP(hipMalloc(d_ptr, bytes));
+  return PT_OK;
+}
+
+int pt_free(void* d_ptr) {
+  PT_HIP(hipFree(d_ptr));
+  return PT_OK;
+}
+
+int pt_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  PT_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+int pt_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  PT_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_memset(void* d_ptr, int value, size_t bytes) {
+  PT_HIP(hipMemset(d_ptr, value, bytes));
+  return PT_OK;
+}
+
+int pt_device_synchronize(void) {
+  PT_HIP(hipDeviceSynchronize());
+  return PT_OK;
+}
+
+void pt_renderer_opts_default(pt_renderer_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->max_bounces = 5;
+  o->rng_mode = PT_RNG_XORWOW;
+  o->persist_rng = 1;
+}
+
+static int setup_random(pt_renderer* r) {
+  if (!r->d_state) return PT_OK;
+  PT_HIP(pt_launch_setup_random(r->d_state, r->width, r->opts.row_begin, r->tile_pixels, r->opts.seed, nullptr));
+  // the reference launches setup_random unchecked and unsynchronised (Renderer.h:38); the
+  // next launch on the same stream orders after it, so no sync is needed here either.
+  return PT_OK;
+}
+
+int pt_renderer_create(int width, int height, int samples_per_pixel, int threads_per_block,
+                       const pt_renderer_opts* opts, pt_renderer** out) {
+  if (!out) return pt_fail(PT_EINVAL, "pt_renderer_create: out is NULL");
+  *out = nullptr;
+  pt_renderer_opts o;
+  if (opts) o = *opts; else pt_renderer_opts_default(&o);
+  if (o.row_begin == 0 && o.row_end == 0) o.row_end = height;
+  if (width <= 0 || height <= 0 || samples_per_pixel <= 0)
+    return pt_fail(PT_EINVAL, "pt_renderer_create: width/height/samples must be positive (%d x %d x %d)", width, height,
+                   samples_per_pixel);
+  if (o.row_begin < 0 || o.row_end > height || o.row_begin > o.row_end)
+    return pt_fail(PT_EINVAL, "pt_renderer_create: bad row range [%d,%d) for height %d", o.row_begin, o.row_end, height);
+  if (o.max_bounces < 0 || o.max_bounces > 64) return pt_fail(PT_EINVAL, "pt_renderer_create: max_bounces %d", o.max_bounces);
+  if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
+    return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
+  // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
+  if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
+
+  int ndev = 0;
+  PT_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return pt_fail(PT_ENODEVICE, "pt_renderer_create: no HIP device");
+
+  pt_renderer* r = new (std::nothrow) pt_renderer();
+  if (!r) return pt_fail(PT_ENOMEM, "pt_renderer_create: out of host memory");
+  r->width = width;
+  r->height = height;
+  r->spp = samples_per_pixel;
+  r->threads_per_block = threads_per_block;
+  r->opts = o;
+  r->tile_pixels = (uint32_t)(o.row_end - o.row_begin) * (uint32_t)width;
+  r->frame = 0;
+  r->d_state = nullptr;
+  r->ev_start = r->ev_stop = nullptr;
+  hipError_t e = hipGetDevice(&r->device);
+  if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
+  if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
+  if (e == hipSuccess && o.rng_mode == PT_RNG_XORWOW && o.persist_rng && r->tile_pixels)
+    e = hipMalloc((void**)&r->d_state, (size_t)r->tile_pixels * 6 * sizeof(uint32_t));  // Renderer.h:37
+  if (e != hipSuccess) {
+    int rc = pt_fail(PT_EHIP, "pt_renderer_create: %s", hipGetErrorString(e));
+    pt_renderer_destroy(r);
+    return rc;
+  }
+  int rc = setup_random(r);  // Renderer.h:38
+  if (rc != PT_OK) {
+    pt_renderer_destroy(r);
+    return rc;
+  }
+  *out = r;
+  return PT_OK;
+}
+
+int pt_renderer_destroy(pt_renderer* r) {
+  if (!r) return PT_OK;
+  if (r->d_state) (void)hipFree(r->d_state);  // Renderer.h:50
+  if (r->ev_start) (void)hipEventDestroy(r->ev_start);
+  if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
+  delete r;
+  return PT_OK;
+}
+
+static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
+                     const float eye[3], PixelKernelArgs* a) {
+  if (!r) return pt_fail(PT_EINVAL, "render: renderer is NULL");
+  if (!d_out && r->tile_pixels) return pt_fail(PT_EINVAL, "render: d_out is NULL");
+  if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "render: bad scene (%d spheres)", n_spheres);
+  if (!basis || !eye) return pt_fail(PT_EINVAL, "render: basis/eye is NULL");
+  if (n_spheres > pt_kernel_max_spheres(r->opts.variant))
+    return pt_fail(PT_ELIMIT, "render: %d spheres exceed the LDS staging limit of %d", n_spheres,
+                   pt_kernel_max_spheres(r->opts.variant));
+  a->out = d_out;
+  a->spheres = d_spheres;
+  a->rng_state = r->d_state;
+  memcpy(a->basis, basis, sizeof(a->basis));
+  memcpy(a->eye, eye, sizeof(a->eye));
+  a->n_spheres = n_spheres;
+  a->width = r->width;
+  a->height = r->height;
+  a->row_begin = r->opts.row_begin;
+  a->tile_pixels = r->tile_pixels;
+  a->spp = r->spp;
+  a->max_bounces = r->opts.max_bounces;
+  a->frame = r->frame;
+  a->seed = r->opts.seed;
+  return PT_OK;
+}
+
+int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
+                        const float eye[3], void* hip_stream) {
+  PixelKernelArgs a;
+  int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
+  if (rc != PT_OK) return rc;
+  if (r->tile_pixels == 0) return PT_OK;
+  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->opts.variant, (hipStream_t)hip_stream));
+  r->frame++;
+  return PT_OK;
+}
+
+int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
+                       const float eye[3], float* ms_out) {
+  PixelKernelArgs a;
+  int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
+  if (rc != PT_OK) return rc;
+  if (ms_out) *ms_out = 0.0f;
+  if (r->tile_pixels == 0) return PT_OK;
+  PT_HIP(hipEventRecord(r->ev_start, nullptr));  // Renderer.h:68
+  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->opts.variant, nullptr));
+  PT_HIP(hipEventRecord(r->ev_stop, nullptr));   // Renderer.h:70
+  PT_HIP(hipEventSynchronize(r->ev_stop));       // Renderer.h:72
+  r->frame++;
+  float ms = 0.0f;
+  PT_HIP(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
+  if (ms_out) *ms_out = ms;
+  return PT_OK;
+}
+
+int pt_renderer_set_frame(pt_renderer* r, uint32_t frame) {
+  if (!r) return pt_fail(PT_EINVAL, "pt_renderer_set_frame: renderer is NULL");
+  r->frame = frame;
+  return PT_OK;
+}
+
+int pt_renderer_reset_rng(pt_renderer* r) {
+  if (!r) return pt_fail(PT_EINVAL, "pt_renderer_reset_rng: renderer is NULL");
+  r->frame = 0;
+  return setup_random(r);
+}
+
+int pt_renderer_get_rng_state(pt_renderer* r, uint32_t* h_state, size_t n_words) {
+  if (!r || !h_state) return pt_fail(PT_EINVAL, "pt_renderer_get_rng_state: NULL argument");
+  if (!r->d_state) return pt_fail(PT_EINVAL, "pt_renderer_get_rng_state: renderer keeps no generator state");
+  if (n_words != (size_t)r->tile_pixels * 6) return pt_fail(PT_EINVAL, "pt_renderer_get_rng_state: expected %zu words", (size_t)r->tile_pixels * 6);
+  PT_HIP(hipMemcpy(h_state, r->d_state, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_renderer_set_rng_state(pt_renderer* r, const uint32_t* h_state, size_t n_words) {
+  if (!r || !h_state) return pt_fail(PT_EINVAL, "pt_renderer_set_rng_state: NULL argument");
+  if (!r->d_state) return pt_fail(PT_EINVAL, "pt_renderer_set_rng_state: renderer keeps no generator state");
+  if (n_words != (size_t)r->tile_pixels * 6) return pt_fail(PT_EINVAL, "pt_renderer_set_rng_state: expected %zu words", (size_t)r->tile_pixels * 6);
+  PT_HIP(hipMemcpy(r->d_state, h_state, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info) {
+  if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
+  hipFuncAttributes fa;
+  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, r->opts.variant)));
+  info->block_threads = PT_BLOCK_THREADS;
+  info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+  info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, r->opts.variant);
+  info->num_vgprs = fa.numRegs;
+  info->num_sgprs = 0;
+  info->scratch_bytes = (int)fa.localSizeBytes;
+  info->max_spheres = pt_kernel_max_spheres(r->opts.variant);
+  return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// pt_device.h -- device-side building blocks of the gfx950 path-trace megakernel.
+//
+// Numeric contract (DESIGN.md "Numeric contract"): every float / double operation below is
+// a single correctly rounded IEEE operation, written in the order the reference writes it
+// (src/pathtrace.cu, cited per function).  This translation unit is compiled with
+// -ffp-contract=off; the only fused operations are the explicit fmaf() calls of pt_sincos,
+// which is this repo's definition of the reference's device sinf/cosf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+struct F3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ F3 mk3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// helper_math.h normalize(v) = v * rsqrtf(dot(v,v)); rsqrtf(x) := 1.0f / sqrtf(x) (contract C2)
+__device__ __forceinline__ F3 normalize(F3 v) {
+  float inv = 1.0f / sqrtf(dot(v, v));
+  return v * inv;
+}
+__device__ __forceinline__ F3 lerp(F3 a, F3 b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+// ---- RNG ---------------------------------------------------------------------------------
+// cuRAND XORWOW (curand_init(seed,0,0) / curand / curand_uniform): src/pathtrace.cu:131,
+// 223-224,265.  Six 32-bit words live in VGPRs for the whole kernel.
+struct Xorwow {
+  uint32_t d, v0, v1, v2, v3, v4;
+};
+
+__device__ __forceinline__ void xorwow_init(Xorwow& s, uint64_t seed) {
+  uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
+  uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+  uint32_t t0 = 1099087573u * s0;
+  uint32_t t1 = 2591861531u * s1;
+  s.d = 6615241u + t1 + t0;
+  s.v0 = 123456789u + t0;
+  s.v1 = 362436069u ^ t0;
+  s.v2 = 521288629u + t1;
+  s.v3 = 88675123u ^ t1;
+  s.v4 = 5783321u + t0;
+}
+
+__device__ __forceinline__ uint32_t xorwow_next(Xorwow& s) {
+  uint32_t t = s.v0 ^ (s.v0 >> 2);
+  s.v0 = s.v1;
+  s.v1 = s.v2;
+  s.v2 = s.v3;
+  s.v3 = s.v4;
+  s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+  s.d += 362437u;
+  return s.v4 + s.d;
+}
+
+// curand_uniform: (0,1]
+__device__ __forceinline__ float uniform_from_u32(uint32_t x) {
+  return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+// Philox4x32-10, counter-based (contract C8): nothing is kept between samples.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// ---- sin/cos on (0, 2*pi] (contract C4) ----------------------------------------------------
+__device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
+  float kf = rintf(x * 6.366197467e-01f);
+  int k = (int)kf;
+  float r = fmaf(-kf, 1.570796371e+00f, x);
+  r = fmaf(-kf, -4.371138829e-08f, r);
+  r = fmaf(-kf, -1.715124510e-15f, r);
+  float r2 = r * r;
+  float ps = fmaf(r2, 2.755731884e-06f, -1.984127011e-04f);
+  ps = fmaf(ps, r2, 8.333333768e-03f);
+  ps = fmaf(ps, r2, -1.666666716e-01f);
+  float sr = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.755731998e-07f, 2.480158764e-05f);
+  pc = fmaf(pc, r2, -1.388888923e-03f);
+  pc = fmaf(pc, r2, 4.166666791e-02f);
+  float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  bool swap = (k & 1) != 0;
+  float ss = swap ? cr : sr;
+  float cc = swap ? sr : cr;
+  // quadrant signs: k&3 = 0:(s,c) 1:(c,-s) 2:(-s,-c) 3:(-c,s)
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+
+// ---- luminance: src/pathtrace.cu:67-69 (double through the literals) -----------------------
+__device__ __forceinline__ float luminance(F3 c) {
+  return (float)(0.2126 * (double)c.x + 0.7152 * (double)c.y + 0.0722 * (double)c.z);
+}
+
+// ---- OnlineVarianceBuffer: src/pathtrace.cu:39-65 -------------------------------------------
+struct Welford {
+  int n;
+  float mean, M2;
+};
+__device__ __forceinline__ void welford_update(Welford& w, float x) {
+  w.n += 1;
+  float delta = x - w.mean;
+  w.mean += delta / (float)w.n;
+  float delta2 = x - w.mean;
+  w.M2 += delta * delta2;
+}
+__device__ __forceinline__ float welford_variance(const Welford& w) {
+  return (w.n < 2) ? 0.0f : w.M2 / (float)(w.n - 1);
+}
+
+// ---- orthoVector / getCosineWeightedNormal: src/pathtrace.cu:121-136 -------------------------
+__device__ __forceinline__ F3 ortho_vector(F3 v) {
+  return (fabsf(v.x) > fabsf(v.z)) ? mk3(-v.y, v.x, 0.0f) : mk3(0.0f, -v.z, v.y);
+}
+
+__device__ __forceinline__ F3 cosine_weighted(F3 dir, float u_az, float u_el) {
+  dir = normalize(dir);
+  F3 o1 = normalize(ortho_vector(dir));
+  F3 o2 = normalize(cross(dir, o1));
+  float rx = u_az * 2.0f * 3.141592654f;
+  float ry = sqrtf(u_el);  // powf(u, 0.5f) := sqrtf(u), contract C3
+  float oneminus = (float)sqrt(1.0 - (double)(ry * ry));
+  float sn, cs;
+  pt_sincos(rx, sn, cs);
+  F3 a = o1 * (cs * oneminus);
+  F3 b = o2 * (sn * oneminus);
+  F3 c = dir * ry;
+  return (a + b) + c;
+}
+
+// ---- intersectSphere: src/pathtrace.cu:72-91 -------------------------------------------------
+// g = {centre.xyz, radius*radius}; a = dot(d,d) is loop-invariant over the sphere list and
+// passed in.  Returns the reference's `*t` through t and its bool through the return value.
+__device__ __forceinline__ bool intersect_sphere(F3 o, F3 d, float a, float4 g, float& t) {
+  F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float b = 2.0f * dot(d, off);  // == (float)(2.0 * (double)dot): scaling by 2 is exact
+  float c = dot(off, off) - g.w;
+  float bb = b * b;
+  float det = bb - 4.0f * a * c;
+  if (det >= 0.0f) {
+    double disc = (double)bb - 4.0 * (double)a * (double)c;
+    double sq = sqrt(disc);
+    double den = 2.0 * (double)a;
+    float tn = (float)(((double)(-b) - sq) / den);
+    float tf = (float)(((double)(-b) + sq) / den);
+    if (tn > 0.0f && tf > 0.0f)
+      t = fminf(tn, tf);
+    else if (tn > 0.0f)
+      t = tn;
+    else
+      t = tf;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace pt

@@ -1,0 +1,37 @@
+// pt_kernel.h -- host-visible interface of the device code in pt_kernel.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ptcore.h"
+
+#define PT_BLOCK_THREADS 256
+// LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
+// use all of it, but we leave room for two resident workgroups).
+#define PT_LDS_BUDGET_BYTES (64 * 1024)
+
+// Everything pixel_kernel needs travels as kernel arguments (SGPRs): the camera is 60 B, so
+// the reference's two per-frame cudaMemcpy H2D (Renderer.h:59-60) disappear.
+struct PixelKernelArgs {
+  float* out;                  // first float of row `row_begin`, layout [row][col][14]
+  const pt_sphere* spheres;    // device, reference 40-byte AoS layout
+  uint32_t* rng_state;         // xorwow: 6 words per tile pixel, or nullptr (fresh generator)
+  float basis[12];             // Camera::getEyeRayBasis corners
+  float eye[3];
+  int32_t n_spheres;
+  int32_t width, height;       // image
+  int32_t row_begin;           // tile origin
+  uint32_t tile_pixels;        // (row_end - row_begin) * width
+  int32_t spp;
+  int32_t max_bounces;
+  uint32_t frame;
+  uint64_t seed;
+};
+
+const void* pt_kernel_symbol(int rng_mode, int variant);
+size_t pt_kernel_lds_bytes(int n_spheres, int variant);
+int pt_kernel_max_spheres(int variant);
+hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);
+hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
+                                  hipStream_t stream);

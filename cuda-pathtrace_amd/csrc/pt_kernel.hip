@@ -1,0 +1,273 @@
+// pt_kernel.hip -- the per-pixel Monte-Carlo megakernel for gfx950 (MI355X).
+//
+// Replaces src/pathtrace.cu's pixel_kernel (:203-257) and setup_random (:259-266).
+// One lane = one pixel, lanes of a wave64 are 64 CONSECUTIVE COLUMNS of one image row
+// (the reference maps adjacent threads to adjacent rows, i.e. a 56*W-byte lane stride).
+// The sphere list is staged once per workgroup into LDS; generator state, ray, throughput,
+// AOV sums and the four Welford accumulators live in VGPRs for the whole frame.
+#include "pt_device.h"
+#include "pt_kernel.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+// LDS image of the scene: geometry and material split so the intersect loop touches
+// 16 B per sphere with a wave-uniform address (LDS broadcast read), and the shading step
+// gathers 32 B by the per-lane hit index.
+struct SceneLds {
+  float4* geom;  // {cx, cy, cz, r*r}
+  float4* mat0;  // {ex, ey, ez, colx}
+  float4* mat1;  // {coly, colz, 0, 0}
+};
+
+__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds) {
+  SceneLds s{lds, lds + n, lds + 2 * n};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const pt_sphere sp = spheres[i];
+    s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
+    s.mat0[i] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], sp.color[0]);
+    s.mat1[i] = make_float4(sp.color[1], sp.color[2], 0.0f, 0.0f);
+  }
+  __syncthreads();
+  return s;
+}
+
+struct TraceOutput {  // src/pathtrace.cu:24-36
+  F3 color, normal, albedo;
+  float depth;
+};
+
+template <int RNG>
+struct Rng;
+
+template <>
+struct Rng<PT_RNG_XORWOW> {
+  Xorwow st;
+  __device__ __forceinline__ void begin_sample(uint32_t) {}
+  __device__ __forceinline__ void jitter(float& jx, float& jy) {
+    jx = uniform_from_u32(xorwow_next(st));
+    jy = uniform_from_u32(xorwow_next(st));
+  }
+  __device__ __forceinline__ void bounce(int, float& az, float& el) {
+    az = uniform_from_u32(xorwow_next(st));  // first draw -> azimuth (contract C5)
+    el = uniform_from_u32(xorwow_next(st));
+  }
+};
+
+template <>
+struct Rng<PT_RNG_PHILOX> {
+  uint32_t k0, k1, pix, sample;
+  uint4 blk;
+  __device__ __forceinline__ void begin_sample(uint32_t s) {
+    sample = s;
+    blk = philox4x32_10(make_uint4(pix, sample, 0u, 0u), k0, k1);
+  }
+  __device__ __forceinline__ void jitter(float& jx, float& jy) {
+    jx = uniform_from_u32(blk.x);
+    jy = uniform_from_u32(blk.y);
+  }
+  __device__ __forceinline__ void bounce(int n, float& az, float& el) {
+    if (n & 1) blk = philox4x32_10(make_uint4(pix, sample, (uint32_t)((n + 1) >> 1), 0u), k0, k1);
+    bool second = (n == 0) || (((n + 1) & 1) != 0);
+    az = uniform_from_u32(second ? blk.z : blk.x);
+    el = uniform_from_u32(second ? blk.w : blk.y);
+  }
+};
+
+// intersectScene: src/pathtrace.cu:93-107
+__device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+  float tNearest = 1000000.0f;
+  float t = 0.0f;
+  bool hit = false;
+  const float a = dot(d, d);
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    if (intersect_sphere(o, d, a, g, t) && t > 0.0f && t < tNearest) {
+      tNearest = t;
+      hit = true;
+      t_hit = t;
+      idx = i;
+    }
+  }
+  return hit;
+}
+
+// trace_ray: src/pathtrace.cu:150-201
+template <int RNG>
+__device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
+                                          Welford (&var)[4], int max_bounces) {
+  F3 color = mk3(0.0f, 0.0f, 0.0f);
+  F3 mask = mk3(1.0f, 1.0f, 1.0f);
+  for (int n = 0; n < max_bounces; n++) {
+    float t = 0.0f;
+    int idx = 0;
+    if (!intersect_scene(sc, nsph, o, d, t, idx)) {  // :157-161
+      L.color = L.color + color;
+      return;
+    }
+    const float4 g = sc.geom[idx];
+    const float4 m0 = sc.mat0[idx];
+    const float4 m1 = sc.mat1[idx];
+    const F3 emis = mk3(m0.x, m0.y, m0.z);
+    const F3 scol = mk3(m0.w, m1.x, m1.y);
+    F3 pos = o + d * t;                                // :163
+    F3 normal = normalize(pos - mk3(g.x, g.y, g.z));   // :164
+    if (!(dot(normal, d) < 0.0f)) normal = normal * -1.0f;  // :166
+    F3 me = mask * emis;
+    if (n == 0)  // :171-172
+      color = color + mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f));
+    else  // :174
+      color = color + me;
+    mask = mask * scol;               // :175
+    o = pos + normal * 0.05f;         // :178, PUSH_RAY_ORIGIN
+    float u_az, u_el;
+    rng.bounce(n, u_az, u_el);
+    d = normalize(cosine_weighted(normal, u_az, u_el));  // :180
+    if (n == 0) {                     // :187-195
+      L.normal = L.normal + normal;
+      L.albedo = L.albedo + scol;
+      L.depth += t;
+      welford_update(var[1], luminance(normal));
+      welford_update(var[2], luminance(scol));
+      welford_update(var[3], t);
+    }
+  }
+  L.color = L.color + color;                    // :198
+  welford_update(var[0], luminance(color));     // :200
+}
+
+// pixel_kernel: src/pathtrace.cu:203-257
+template <int RNG>
+__global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel(PixelKernelArgs a) {
+  extern __shared__ float4 lds_scene[];
+  const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
+
+  const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;  // pixel index inside the tile
+  if (tp >= a.tile_pixels) return;
+  const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
+  const int col = (int)(tp % (uint32_t)a.width);
+  const uint32_t id = (uint32_t)row * (uint32_t)a.width + (uint32_t)col;  // :206
+
+  Rng<RNG> rng;
+  if constexpr (RNG == PT_RNG_XORWOW) {
+    if (a.rng_state) {  // :212
+      const uint32_t* s = a.rng_state + (size_t)tp * 6;
+      rng.st = Xorwow{s[0], s[1], s[2], s[3], s[4], s[5]};
+    } else {
+      xorwow_init(rng.st, (uint64_t)id + a.seed);  // :265
+    }
+  } else {
+    rng.k0 = (uint32_t)a.seed;
+    rng.k1 = (uint32_t)(a.seed >> 32) ^ a.frame;
+    rng.pix = id;
+  }
+
+  const F3 B0 = mk3(a.basis[0], a.basis[1], a.basis[2]), B1 = mk3(a.basis[3], a.basis[4], a.basis[5]);
+  const F3 B2 = mk3(a.basis[6], a.basis[7], a.basis[8]), B3 = mk3(a.basis[9], a.basis[10], a.basis[11]);
+  const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
+
+  Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
+  TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
+
+  for (int i = 0; i < a.spp; i++) {  // :219
+    rng.begin_sample((uint32_t)i);
+    float sx = (float)row, sy = (float)col;  // :221
+    if (a.spp != 1) {                        // :222-225
+      float jx, jy;
+      rng.jitter(jx, jy);
+      sx += jx * 1.0f - 0.5f;
+      sy += jy * 1.0f - 0.5f;
+    }
+    sx /= (float)a.height;  // :226 (contract C7)
+    sy /= (float)a.width;
+    F3 dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);  // :229
+    trace_ray<RNG>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+  }
+
+  const float fs = (float)a.spp;  // :234-237
+  float* o = a.out + (size_t)tp * 14;
+  o[0] = L.color.x / fs;
+  o[1] = L.color.y / fs;
+  o[2] = L.color.z / fs;
+  o[3] = L.normal.x / fs;
+  o[4] = L.normal.y / fs;
+  o[5] = L.normal.z / fs;
+  o[6] = L.albedo.x / fs;
+  o[7] = L.albedo.y / fs;
+  o[8] = L.albedo.z / fs;
+  o[9] = L.depth / fs;
+  o[10] = welford_variance(var[0]);  // :251-254
+  o[11] = welford_variance(var[1]);
+  o[12] = welford_variance(var[2]);
+  o[13] = welford_variance(var[3]);
+
+  if constexpr (RNG == PT_RNG_XORWOW) {
+    if (a.rng_state) {  // :256
+      uint32_t* s = a.rng_state + (size_t)tp * 6;
+      s[0] = rng.st.d;
+      s[1] = rng.st.v0;
+      s[2] = rng.st.v1;
+      s[3] = rng.st.v2;
+      s[4] = rng.st.v3;
+      s[5] = rng.st.v4;
+    }
+  }
+}
+
+// setup_random: src/pathtrace.cu:259-266
+__global__ void __launch_bounds__(PT_BLOCK_THREADS)
+    setup_random_kernel(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed) {
+  const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
+  if (tp >= tile_pixels) return;
+  const uint32_t id = (uint32_t)(row_begin + (int)(tp / (uint32_t)width)) * (uint32_t)width + tp % (uint32_t)width;
+  Xorwow s;
+  xorwow_init(s, (uint64_t)id + seed);
+  uint32_t* p = state + (size_t)tp * 6;
+  p[0] = s.d;
+  p[1] = s.v0;
+  p[2] = s.v1;
+  p[3] = s.v2;
+  p[4] = s.v3;
+  p[5] = s.v4;
+}
+
+}  // namespace pt
+
+// ---- launchers (host) ---------------------------------------------------------------------
+static inline size_t scene_lds_bytes(int n) { return (size_t)n * 3 * sizeof(float4); }
+
+const void* pt_kernel_symbol(int rng_mode, int variant) {
+  (void)variant;
+  return rng_mode == PT_RNG_PHILOX ? (const void*)pt::pixel_kernel<PT_RNG_PHILOX>
+                                   : (const void*)pt::pixel_kernel<PT_RNG_XORWOW>;
+}
+
+size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
+  (void)variant;
+  return scene_lds_bytes(n_spheres);
+}
+
+int pt_kernel_max_spheres(int variant) {
+  (void)variant;
+  return (int)(PT_LDS_BUDGET_BYTES / (3 * sizeof(float4)));
+}
+
+hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
+  (void)variant;
+  const unsigned grid = (a.tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
+  const size_t lds = scene_lds_bytes(a.n_spheres);
+  if (rng_mode == PT_RNG_PHILOX)
+    hipLaunchKernelGGL(pt::pixel_kernel<PT_RNG_PHILOX>, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, a);
+  else
+    hipLaunchKernelGGL(pt::pixel_kernel<PT_RNG_XORWOW>, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
+                                  hipStream_t stream) {
+  const unsigned grid = (tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
+  hipLaunchKernelGGL(pt::setup_random_kernel, dim3(grid), dim3(PT_BLOCK_THREADS), 0, stream, state, width, row_begin,
+                     tile_pixels, seed);
+  return hipGetLastError();
+}

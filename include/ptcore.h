@@ -1,0 +1,161 @@
+/*
+ * ptcore.h -- C ABI of libptcore.so: the MI355X (gfx950) implementation of the per-pixel
+ * Monte-Carlo path-trace megakernel of trevor-m/cuda-pathtrace.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer; its boundary for this path
+ * is header-level C++ (include/pathtrace.h, include/Renderer.h, include/OutputBuffer.h,
+ * include/Scene.h).  Every entry point below names the reference interface it replaces
+ * (file:line under the reference tree).  Plain pointers and sizes only; no C++ or torch
+ * types.  The C++ look-alike classes that forward to these functions live in
+ * cuda-pathtrace_amd/host/ (Renderer.h, OutputBuffer.h, Scene.h, Camera.h) and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns PT_OK (0) or a negative PT_E* code; pt_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.  The reference's
+ *     gpuErrchk (include/CudaErrorCheck.h:6-14) prints "GPUassert: <msg> <file> <line>"
+ *     and exit()s; the C++ look-alikes reproduce that on a non-zero return.
+ *   - "d_" pointers are device (HBM) addresses of the currently selected device; they may
+ *     be foreign allocations (e.g. a torch CUDA tensor's data_ptr, as main.cu:104,134 does).
+ *   - output layout is the reference's: float32 [row][col][14], channels
+ *     0-2 colour RGB, 3-5 normal XYZ, 6-8 albedo RGB, 9 depth, 10 colourVar, 11 normalVar,
+ *     12 albedoVar, 13 depthVar (src/pathtrace.cu:240-254).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     fails with PT_ENODEVICE / PT_EHIP.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+enum {
+  PT_OK = 0,
+  PT_EINVAL = -1,    /* bad argument                                         */
+  PT_EHIP = -2,      /* a HIP runtime call failed (message has hipGetErrorString) */
+  PT_ENODEVICE = -3, /* no HIP device visible                                */
+  PT_ENOMEM = -4,    /* host allocation failed                               */
+  PT_ELIMIT = -5     /* scene does not fit the kernel's LDS staging budget   */
+};
+
+/* struct Sphere, include/Scene.h:7-14 -- same 40-byte layout, so a reference
+ * `Sphere*` can be passed unchanged. */
+typedef struct pt_sphere {
+  float radius;
+  float pos[3];
+  float emission[3];
+  float color[3];
+} pt_sphere;
+
+enum {
+  PT_RNG_XORWOW = 0, /* cuRAND XORWOW, seed = pixel id (src/pathtrace.cu:265): reference parity */
+  PT_RNG_PHILOX = 1  /* counter-based Philox4x32-10 keyed on (seed, frame); stateless           */
+};
+
+/* Options that the reference hard-codes or keeps in Renderer; zero-initialise then call
+ * pt_renderer_opts_default(). */
+typedef struct pt_renderer_opts {
+  int32_t max_bounces;  /* MAX_BOUNCES, src/pathtrace.cu:7 (default 5)                     */
+  int32_t rng_mode;     /* PT_RNG_*  (default PT_RNG_XORWOW)                               */
+  uint64_t seed;        /* xorwow: added to the pixel id (0 = reference); philox: key      */
+  int32_t row_begin;    /* rows [row_begin,row_end) of the width x height image are        */
+  int32_t row_end;      /*   rendered by this renderer (multi-GPU row tiling); 0,0 = all   */
+  int32_t persist_rng;  /* xorwow only: keep per-pixel generator state across Render()     */
+                        /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
+  int32_t variant;      /* kernel variant, 0 = default (see pt_kernel_variants)            */
+} pt_renderer_opts;
+
+typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */
+
+/* ---- library / device -------------------------------------------------------------- */
+int pt_abi_version(void);
+const char* pt_last_error(void);
+/* cudaSetDevice(cudaDevice), src/main.cu:86 */
+int pt_set_device(int device);
+int pt_device_count(int* count);
+/* name + CU count of the selected device (for bench / logs) */
+int pt_device_info(char* name, size_t name_len, int* compute_units, int* clock_khz);
+
+/* ---- device memory: OutputBuffer / Scene allocations --------------------------------- */
+/* cudaMalloc in OutputBuffer::AllocateGPU (OutputBuffer.h:73-74) and Scene() (Scene.h:36) */
+int pt_malloc(void** d_ptr, size_t bytes);
+/* cudaFree in OutputBuffer::FreeGPU (OutputBuffer.h:108-109) */
+int pt_free(void* d_ptr);
+/* cudaMemcpy H2D in Scene() (Scene.h:37) */
+int pt_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+/* cudaMemcpy D2H in OutputBuffer::CopyFromGPU (OutputBuffer.h:49-50) */
+int pt_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int pt_memset(void* d_ptr, int value, size_t bytes);
+int pt_device_synchronize(void);
+
+/* ---- Renderer ------------------------------------------------------------------------ */
+void pt_renderer_opts_default(pt_renderer_opts* opts);
+
+/* Renderer::Renderer(width, height, samplesPerPixel, numThreads), Renderer.h:23-46.
+ * Allocates the per-pixel generator state and runs setup_random (pathtrace.cu:259-266)
+ * when rng_mode == PT_RNG_XORWOW && persist_rng.  threads_per_block is accepted for CLI
+ * compatibility (main.cu:21,34) and ignored: the kernel picks its own workgroup shape.
+ * opts may be NULL (= defaults). */
+int pt_renderer_create(int width, int height, int samples_per_pixel, int threads_per_block,
+                       const pt_renderer_opts* opts, pt_renderer** out);
+
+/* Renderer::~Renderer(), Renderer.h:48-53 */
+int pt_renderer_destroy(pt_renderer* r);
+
+/* Renderer::Render(OutputBuffer d_buffer, const Scene& d_scene, const Camera& camera),
+ * Renderer.h:55-76.  d_out points at the first float of row `row_begin` (for a full-frame
+ * renderer: the buffer base).  basis = the 4 corner directions of
+ * Camera::getEyeRayBasis (Camera.h:125-149), eye = camera.Position.  Synchronous like the
+ * reference (returns after the stop event), *ms_out = kernel-only milliseconds from a
+ * hipEvent pair (Renderer.h:63-75).  ms_out may be NULL. */
+int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
+                       const float basis[12], const float eye[3], float* ms_out);
+
+/* Same launch without host synchronisation, on the caller's HIP stream (hipStream_t passed
+ * as void*; NULL = the default stream).  Used by bench.py and the multi-GPU driver so the
+ * kernel overlaps with the caller's copies/collectives and can be timed with the caller's
+ * events.  The camera (60 B) travels as kernel arguments: no H2D copy, no allocation. */
+int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
+                        const float basis[12], const float eye[3], void* hip_stream);
+
+/* Frame counter used by the philox key; incremented by every render/enqueue. */
+int pt_renderer_set_frame(pt_renderer* r, uint32_t frame);
+/* Re-run setup_random (pathtrace.cu:259-266): generator state as after construction. */
+int pt_renderer_reset_rng(pt_renderer* r);
+/* Copy the xorwow state ({d,v0..v4} = 6 x uint32 per tile pixel) to / from the host. */
+int pt_renderer_get_rng_state(pt_renderer* r, uint32_t* h_state, size_t n_words);
+int pt_renderer_set_rng_state(pt_renderer* r, const uint32_t* h_state, size_t n_words);
+/* Static facts about the compiled kernel the renderer will launch. */
+typedef struct pt_kernel_info {
+  int32_t block_threads;
+  int32_t grid_blocks;
+  int32_t lds_bytes;
+  int32_t num_vgprs;    /* from hipFuncGetAttributes */
+  int32_t num_sgprs;
+  int32_t scratch_bytes;
+  int32_t max_spheres;  /* LDS staging limit for this variant */
+} pt_kernel_info;
+int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info);
+
+/* ---- host-side inputs of the path ------------------------------------------------------ */
+/* The 9 spheres Scene() hard-codes, include/Scene.h:26-34 (host array). */
+int pt_scene_cornell(pt_sphere out[9]);
+/* Seeded random-sphere scene for BASELINE.json config 4 (no reference counterpart):
+ * n spheres inside the Cornell box volume; with_walls != 0 appends nothing but makes the
+ * first 6 entries the wall spheres of Scene.h:26-31 and the 7th the light (closed scene). */
+int pt_scene_random(int n, uint64_t seed, int with_walls, pt_sphere* out);
+/* Camera::updateCameraVectors + Camera::getEyeRayBasis, include/Camera.h:125-149,153-164,
+ * restated without glm (float32, same operation order as glm 0.9.8). */
+int pt_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int width, int height,
+                    float basis_out[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */
