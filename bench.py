@@ -34,8 +34,13 @@ def cpu_baseline(oracle, spheres, basis, rows):
     """Oracle (CPU restatement, kind 'port') on all host cores over a bounded sample of the
     same workload: a band of `rows` image rows at the full 1024 columns x 1024 spp."""
     cores = os.cpu_count() or 1
+    if rows <= 0:  # size the sample for about 10 s of wall time from a short probe, capped at the full frame
+        t = time.perf_counter()
+        oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=HEIGHT // 2, row_end=HEIGHT // 2 + 4,
+                      threads=cores)
+        rate = 4 * WIDTH * SPP / (time.perf_counter() - t)
+        rows = int(max(8, min(HEIGHT, 10.0 * rate / (WIDTH * SPP))))
     r0 = HEIGHT // 2 - rows // 2
-    oracle.render(WIDTH, HEIGHT, 4, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + 1, threads=cores)  # warm
     t = time.perf_counter()
     oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores)
     dt = time.perf_counter() - t
@@ -59,7 +64,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--spp", type=int, default=SPP, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=48)
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~10 s)")
     args = ap.parse_args()
 
     import torch

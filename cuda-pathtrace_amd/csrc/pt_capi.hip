@@ -131,6 +131,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.max_bounces < 0 || o.max_bounces > 64) return pt_fail(PT_EINVAL, "pt_renderer_create: max_bounces %d", o.max_bounces);
   if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
     return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
+  if (o.variant < 0 || o.variant >= pt_kernel_num_variants())
+    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d (have %d)", o.variant, pt_kernel_num_variants());
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
 

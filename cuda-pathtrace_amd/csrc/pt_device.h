@@ -174,4 +174,88 @@ __device__ __forceinline__ bool intersect_sphere(F3 o, F3 d, float a, float4 g, 
   return false;
 }
 
+// ---- variant 1: the same values from fewer FP64 instructions -----------------------------------
+// Everything below returns bit-for-bit what intersect_sphere() returns; only the instruction
+// sequence differs.  Per bounce the ray direction is fixed, so den = 2.0*a and an almost
+// correctly rounded reciprocal of it are computed once (RayConst) and shared by all spheres.
+struct RayConst {
+  float a;      // dot(d,d)
+  float a4;     // 4.0f*a (exact)
+  double a4d;   // 4.0*(double)a (exact)
+  double den;   // 2.0*(double)a (exact)
+  double rden;  // ~1/den, <= 1 ulp
+};
+
+__device__ __forceinline__ RayConst make_ray_const(F3 d) {
+  RayConst rc;
+  rc.a = dot(d, d);
+  rc.a4 = 4.0f * rc.a;
+  rc.a4d = 4.0 * (double)rc.a;
+  rc.den = 2.0 * (double)rc.a;
+  double r = __builtin_amdgcn_rcp(rc.den);
+  double e = __builtin_fma(-rc.den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-rc.den, r, 1.0);
+  rc.rden = __builtin_fma(r, e, r);
+  return rc;
+}
+
+// Correctly rounded sqrt for x in [2^-600, 2^600]: the Newton core hipcc itself emits for
+// sqrt(double) (v_rsq_f64 + Goldschmidt/Newton with fma residuals) without its range
+// scaling; anything else (zero, negative, tiny, huge, inf, NaN) takes the library call.
+__device__ __forceinline__ double sqrt_cr(double x) {
+  const uint32_t hi = (uint32_t)__double2hiint(x);
+  if (__builtin_expect(((hi >> 20) - 423u) >= 1200u, 0)) return sqrt(x);
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+
+// (float)(num / den) with den = rc.den.  q = Markstein quotient from the shared reciprocal is
+// within 1 ulp(double) of the correctly rounded quotient; the float it rounds to can differ
+// from the reference's only if q lies within a few double-ulps of a float rounding boundary
+// (low 29 mantissa bits == 0x10000000) or outside the float normal range -- those lanes
+// (about 3e-8 of all quotients) redo the division literally.
+__device__ __forceinline__ float quotient_to_float(double num, const RayConst& rc) {
+  double q = num * rc.rden;
+  double rem = __builtin_fma(-q, rc.den, num);
+  q = __builtin_fma(rem, rc.rden, q);
+  const uint32_t lo = (uint32_t)__double2loint(q), hi = (uint32_t)__double2hiint(q);
+  const bool near_boundary = ((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u;
+  const bool out_of_range = (((hi >> 20) & 0x7FFu) - 903u) >= 247u;
+  if (__builtin_expect(near_boundary || out_of_range, 0)) q = num / rc.den;
+  return (float)q;
+}
+
+__device__ __forceinline__ bool intersect_sphere_v1(F3 o, F3 d, const RayConst& rc, float4 g, float& t) {
+  F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float b = 2.0f * dot(d, off);
+  float c = dot(off, off) - g.w;
+  float bb = b * b;
+  float det = bb - rc.a4 * c;
+  if (det >= 0.0f) {
+    double disc = (double)bb - rc.a4d * (double)c;
+    double sq = sqrt_cr(disc);
+    double nb = (double)(-b);
+    float tn = quotient_to_float(nb - sq, rc);
+    float tf = quotient_to_float(nb + sq, rc);
+    if (tn > 0.0f && tf > 0.0f)
+      t = fminf(tn, tf);
+    else if (tn > 0.0f)
+      t = tn;
+    else
+      t = tf;
+    return true;
+  }
+  return false;
+}
+
 }  // namespace pt

@@ -29,6 +29,7 @@ struct PixelKernelArgs {
   uint64_t seed;
 };
 
+int pt_kernel_num_variants(void);
 const void* pt_kernel_symbol(int rng_mode, int variant);
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);

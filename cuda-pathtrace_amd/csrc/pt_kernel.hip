@@ -76,14 +76,20 @@ struct Rng<PT_RNG_PHILOX> {
 };
 
 // intersectScene: src/pathtrace.cu:93-107
+template <int VAR>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   float tNearest = 1000000.0f;
   float t = 0.0f;
   bool hit = false;
-  const float a = dot(d, d);
+  const RayConst rc = make_ray_const(d);
   for (int i = 0; i < n; i++) {
     const float4 g = sc.geom[i];
-    if (intersect_sphere(o, d, a, g, t) && t > 0.0f && t < tNearest) {
+    bool h;
+    if constexpr (VAR == 0)
+      h = intersect_sphere(o, d, rc.a, g, t);
+    else
+      h = intersect_sphere_v1(o, d, rc, g, t);
+    if (h && t > 0.0f && t < tNearest) {
       tNearest = t;
       hit = true;
       t_hit = t;
@@ -94,7 +100,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
 }
 
 // trace_ray: src/pathtrace.cu:150-201
-template <int RNG>
+template <int RNG, int VAR>
 __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
                                           Welford (&var)[4], int max_bounces) {
   F3 color = mk3(0.0f, 0.0f, 0.0f);
@@ -102,7 +108,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
   for (int n = 0; n < max_bounces; n++) {
     float t = 0.0f;
     int idx = 0;
-    if (!intersect_scene(sc, nsph, o, d, t, idx)) {  // :157-161
+    if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
       L.color = L.color + color;
       return;
     }
@@ -138,7 +144,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
 }
 
 // pixel_kernel: src/pathtrace.cu:203-257
-template <int RNG>
+template <int RNG, int VAR>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
   const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel(PixelKernelArgs
     sx /= (float)a.height;  // :226 (contract C7)
     sy /= (float)a.width;
     F3 dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);  // :229
-    trace_ray<RNG>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+    trace_ray<RNG, VAR>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
   }
 
   const float fs = (float)a.spp;  // :234-237
@@ -237,11 +243,20 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 // ---- launchers (host) ---------------------------------------------------------------------
 static inline size_t scene_lds_bytes(int n) { return (size_t)n * 3 * sizeof(float4); }
 
-const void* pt_kernel_symbol(int rng_mode, int variant) {
-  (void)variant;
-  return rng_mode == PT_RNG_PHILOX ? (const void*)pt::pixel_kernel<PT_RNG_PHILOX>
-                                   : (const void*)pt::pixel_kernel<PT_RNG_XORWOW>;
+typedef void (*pixel_kernel_fn)(PixelKernelArgs);
+
+static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
+  const bool philox = rng_mode == PT_RNG_PHILOX;
+  switch (variant) {
+    case 0: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 0> : pt::pixel_kernel<PT_RNG_XORWOW, 0>;
+    case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
+    default: return nullptr;
+  }
 }
+
+int pt_kernel_num_variants(void) { return 2; }
+
+const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
   (void)variant;
@@ -254,13 +269,10 @@ int pt_kernel_max_spheres(int variant) {
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
-  (void)variant;
+  pixel_kernel_fn fn = select_kernel(rng_mode, variant);
+  if (!fn) return hipErrorInvalidValue;
   const unsigned grid = (a.tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
-  const size_t lds = scene_lds_bytes(a.n_spheres);
-  if (rng_mode == PT_RNG_PHILOX)
-    hipLaunchKernelGGL(pt::pixel_kernel<PT_RNG_PHILOX>, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, a);
-  else
-    hipLaunchKernelGGL(pt::pixel_kernel<PT_RNG_XORWOW>, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), scene_lds_bytes(a.n_spheres), stream, a);
   return hipGetLastError();
 }
 

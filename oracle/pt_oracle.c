@@ -486,21 +486,23 @@ static void render_pixel(const pto_params* p, const pto_sphere* sph, int nsph, c
 }
 
 /* ------------------------------------------------------------------ driver ------------- */
+#define PTO_CHUNK 64 /* pixels per work item: fine enough to keep hundreds of host threads busy */
 typedef struct {
   const pto_params* p; const pto_sphere* sph; int nsph; v3 B[4]; v3 eye;
-  float* out; uint32_t* state; volatile int next_row;
+  float* out; uint32_t* state; volatile long next_chunk; long n_chunks; long tile_pixels;
 } job_t;
 
 static void* worker(void* arg) {
   job_t* j = (job_t*)arg;
   const pto_params* p = j->p;
   for (;;) {
-    int row = __sync_fetch_and_add(&j->next_row, 1);
-    if (row >= p->row_end) break;
-    for (int col = 0; col < p->width; col++) {
-      size_t tp = (size_t)(row - p->row_begin) * (size_t)p->width + (size_t)col;
-      render_pixel(p, j->sph, j->nsph, j->B, j->eye, row, col, j->out + tp * 14,
-                   j->state ? j->state + tp * 6 : NULL);
+    long ch = __sync_fetch_and_add(&j->next_chunk, 1L);
+    if (ch >= j->n_chunks) break;
+    long tp_end = (ch + 1) * PTO_CHUNK < j->tile_pixels ? (ch + 1) * PTO_CHUNK : j->tile_pixels;
+    for (long tp = ch * PTO_CHUNK; tp < tp_end; tp++) {
+      int row = p->row_begin + (int)(tp / p->width), col = (int)(tp % p->width);
+      render_pixel(p, j->sph, j->nsph, j->B, j->eye, row, col, j->out + (size_t)tp * 14,
+                   j->state ? j->state + (size_t)tp * 6 : NULL);
     }
   }
   return NULL;
@@ -519,7 +521,9 @@ int pto_render(const pto_params* p, const pto_sphere* spheres, int n_spheres, co
   j.p = p; j.sph = spheres; j.nsph = n_spheres; j.out = out; j.state = rng_state;
   for (int k = 0; k < 4; k++) j.B[k] = mk3(basis[3 * k], basis[3 * k + 1], basis[3 * k + 2]);
   j.eye = mk3(eye[0], eye[1], eye[2]);
-  j.next_row = p->row_begin;
+  j.tile_pixels = (long)(p->row_end - p->row_begin) * (long)p->width;
+  j.n_chunks = (j.tile_pixels + PTO_CHUNK - 1) / PTO_CHUNK;
+  j.next_chunk = 0;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   if (n_threads == 1) { worker(&j); return 0; }

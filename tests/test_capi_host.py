@@ -1,0 +1,94 @@
+"""CPU tests of the C ABI: the library loads, exports every symbol include/ptcore.h declares,
+validates arguments, produces the host-side inputs (scene tables, camera basis) identically to
+the oracle, and FAILS LOUDLY (no fallback) when asked to compute without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pt):
+    names = declared_symbols()
+    assert len(names) >= 24
+    raw = ctypes.CDLL(pt.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+    # and the ctypes table used by tests/bench covers the whole header
+    assert sorted(pt.ABI) == names
+
+
+def test_abi_version_and_struct_layout(pt):
+    assert pt.lib.pt_abi_version() == 1
+    assert pt.SPHERE_DTYPE.itemsize == 40          # include/Scene.h:7-14
+    assert ctypes.sizeof(pt.RendererOpts) == 32
+    o = pt.RendererOpts()
+    pt.lib.pt_renderer_opts_default(ctypes.byref(o))
+    assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant) == (5, 0, 0, 1, o.variant)
+
+
+def test_cornell_scene_matches_oracle_table(pt, oracle):
+    assert pt.scene_cornell().tobytes() == oracle.scene_cornell().tobytes()
+    s = pt.scene_cornell()
+    assert s["radius"][8] == 600.0 and tuple(s["emission"][8]) == (4.0, np.float32(3.6), np.float32(3.2))
+
+
+def test_random_scene_is_seeded_and_bounded(pt):
+    a, b, c = pt.scene_random(1000, seed=7), pt.scene_random(1000, seed=7), pt.scene_random(1000, seed=8)
+    assert a.tobytes() == b.tobytes() and a.tobytes() != c.tobytes()
+    assert a[:6].tobytes() == pt.scene_cornell()[:6].tobytes() and a[6].tobytes() == pt.scene_cornell()[8].tobytes()
+    r = a[7:]
+    assert (r["radius"] >= 0.5).all() and (r["radius"] < 3.0).all()
+    assert (r["pos"][:, 0] >= 1).all() and (r["pos"][:, 0] < 99).all()
+    assert (r["pos"][:, 2] >= 0).all() and (r["pos"][:, 2] < 170).all()
+    assert 0 < (r["emission"][:, 0] > 0).sum() < 40
+    op = pt.scene_random(50, seed=7, with_walls=False)
+    assert (op["radius"] < 3.0).all()
+    with pytest.raises(pt.PtError):
+        pt.scene_random(3, seed=1, with_walls=True)
+
+
+@pytest.mark.parametrize("pose", [((50.0, 52.0, 295.6), -90.0, 0.0), ((10.0, 20.0, 30.0), -45.0, 10.0),
+                                  ((50.0, 52.0, 100.0), -120.0, -25.0)])
+def test_camera_basis_matches_oracle_bitwise(pt, oracle, pose):
+    pos, yaw, pitch = pose
+    for w, h in ((256, 256), (1024, 1024)):
+        a = pt.camera_basis(pos, yaw, pitch, w, h)
+        b = oracle.camera_basis(pos, yaw, pitch, w, h)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_argument_validation(pt):
+    for bad in (dict(width=0), dict(spp=0), dict(max_bounces=-1), dict(rng_mode=7), dict(row_begin=5, row_end=3),
+                dict(row_begin=0, row_end=99), dict(variant=999)):
+        kw = dict(width=16, height=16, spp=1)
+        kw.update(bad)
+        w, h, spp = kw.pop("width"), kw.pop("height"), kw.pop("spp")
+        with pytest.raises(pt.PtError) as e:
+            pt.Renderer(w, h, spp, **kw)
+        assert e.value.code == -1, (bad, str(e.value))
+
+
+def test_compute_fails_loudly_without_gpu(pt):
+    """No CPU fallback: on a machine without a HIP device every compute entry point errors."""
+    try:
+        n = pt.device_count()
+    except pt.PtError as e:
+        n = 0
+        assert e.code in (-2, -3)
+    if n > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pt.PtError) as e:
+        pt.Renderer(16, 16, 1)
+    assert e.value.code in (-2, -3) and "device" in str(e.value).lower()
+    with pytest.raises(pt.PtError):
+        pt.DeviceBuffer(1024)

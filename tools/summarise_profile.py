@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag> (written by tools/profile.sh) into profiles/<round>/<tag>.md
++ .json: kernel-trace stats, PMC counters per launch of pt::pixel_kernel, HBM traffic with the
+gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x2 for wide coalesced reads is NOT applied
+here because this kernel's reads are 40-byte scene records and 24-byte state words, not
+16-B/lane streams -- the raw and the doubled value are both reported)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+out = {"tag": tag}
+
+st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    out["kernel_stats"] = rows
+    open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write(open(st[0]).read())
+
+def pmc(sub):
+    acc = {}
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "pixel_kernel" not in r["Kernel_Name"]:
+                continue
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+counters = {}
+for sub in ("pmc_sq", "pmc_sq2", "pmc_write", "pmc_fetch"):
+    c, n = pmc(sub)
+    counters.update(c)
+out["pmc_per_launch_avg"] = counters
+if "WRITE_SIZE" in counters or "FETCH_SIZE" in counters:
+    w = counters.get("WRITE_SIZE", 0.0) * 1024
+    f = counters.get("FETCH_SIZE", 0.0) * 1024
+    out["hbm_bytes_per_launch"] = {"write": w, "fetch_raw": f, "fetch_x2": 2 * f, "total_raw": w + f}
+if counters.get("SQ_BUSY_CYCLES") and counters.get("SQ_ACTIVE_INST_VALU"):
+    out["derived"] = {
+        "valu_inst_per_wave": counters.get("SQ_INSTS_VALU", 0) / max(counters.get("SQ_WAVES", 1), 1),
+        "active_inst_valu_over_wave_cycles": counters["SQ_ACTIVE_INST_VALU"] / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
+        "wait_inst_any_over_wave_cycles": counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
+        "wait_any_over_wave_cycles": counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
+    }
+for log in ("stats.log",):
+    p = os.path.join(src, log)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith('{"metric"'):
+                out["bench_line_under_profiler"] = json.loads(line)
+json.dump(out, open(os.path.join(dst, f"{tag}.json"), "w"), indent=1)
+print(json.dumps({k: out[k] for k in out if k != "bench_line_under_profiler"}, indent=1))
