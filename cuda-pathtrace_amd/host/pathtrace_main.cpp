@@ -1,0 +1,141 @@
+// pathtrace_main.cpp -- command-line front end equivalent to the single-frame mode of
+// src/main.cu:18-83,179-193, written against the look-alike headers exactly as main.cu is
+// written against the reference's (Scene / Renderer / Camera / OutputBuffer).
+// Same flags, defaults, banner and timing line; -i/-d (OpenGL window, embedded-Python CNN
+// denoiser) are accepted and reported as unsupported: both are out of scope.
+// Additions: --rng, --max-bounces, --spheres N (seeded random scene), --frames N (headless
+// stand-in for the interactive loop main.cu:146-177: N x Render() into the same device buffer).
+#include <stdlib.h>
+#include <string.h>
+
+#include <iostream>
+#include <string>
+
+#include "Camera.h"
+#include "OutputBuffer.h"
+#include "Renderer.h"
+#include "Scene.h"
+
+static void usage() {
+  std::cout << "cuda-pathtrace" << std::endl
+            << "Options:\n"
+               "  -h [ --help ]                 Print help messages\n"
+               "  -t [ --threads-per-block ] arg Number of threads per block in 2D CUDA scheduling grid. (ignored)\n"
+               "  --size arg                    Size of the screen in pixels\n"
+               "  -s [ --samples ] arg          Number of samples per pixel\n"
+               "  --device arg                  Which device to use for rendering\n"
+               "  -d [ --denoising ]            Use denoising neural network. (unsupported)\n"
+               "  -i [ --interactive ]          Interactive mode (unsupported; see --frames)\n"
+               "  --nobitmap                    Don't output bitmaps for each channel\n"
+               "  -o [ --output ] arg           Prefix of output file/path\n"
+               "  -x [ --camera-x ] arg         Starting camera position x\n"
+               "  -y [ --camera-y ] arg         Starting camera position y\n"
+               "  -z [ --camera-z ] arg         Starting camera position z\n"
+               "  -c [ --camera-yaw ] arg       Starting camera view yaw\n"
+               "  -p [ --camera-pitch ] arg     Starting camera view pitch\n"
+               "  --rng arg                     xorwow (default, reference parity) | philox\n"
+               "  --max-bounces arg             path length cap (default 5)\n"
+               "  --spheres arg                 render a seeded random scene of N spheres\n"
+               "  --frames arg                  render N frames back to back (headless interactive loop)\n"
+            << std::endl;
+}
+
+int main(int argc, const char** argv) {
+  // default arguments (main.cu:20-29)
+  int size = 512;
+  int threadsPerBlock = 8;
+  int samplesPerPixel = 4;
+  int cudaDevice = 0;
+  float cameraPos[3] = {50.0f, 52.0f, 295.6f};
+  float cameraView[2] = {-90.0f, 0.0f};
+  bool denoising = false, interactive = false, noBitmap = false;
+  std::string outputName = "output/out";
+  std::string rng = "xorwow";
+  int maxBounces = 5, nSpheres = 0, frames = 1;
+
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto value = [&](const char* what) -> const char* {
+      if (i + 1 >= argc) {
+        std::cerr << "ERROR: the required argument for option '" << what << "' is missing" << std::endl << std::endl;
+        usage();
+        exit(1);
+      }
+      return argv[++i];
+    };
+    if (a == "-h" || a == "--help") { usage(); return 0; }
+    else if (a == "-t" || a == "--threads-per-block") threadsPerBlock = atoi(value("--threads-per-block"));
+    else if (a == "--size") size = atoi(value("--size"));
+    else if (a == "-s" || a == "--samples") samplesPerPixel = atoi(value("--samples"));
+    else if (a == "--device") cudaDevice = atoi(value("--device"));
+    else if (a == "-d" || a == "--denoising") denoising = true;
+    else if (a == "-i" || a == "--interactive") interactive = true;
+    else if (a == "--nobitmap") noBitmap = true;
+    else if (a == "-o" || a == "--output") outputName = value("--output");
+    else if (a == "-x" || a == "--camera-x") cameraPos[0] = (float)atof(value("--camera-x"));
+    else if (a == "-y" || a == "--camera-y") cameraPos[1] = (float)atof(value("--camera-y"));
+    else if (a == "-z" || a == "--camera-z") cameraPos[2] = (float)atof(value("--camera-z"));
+    else if (a == "-c" || a == "--camera-yaw") cameraView[0] = (float)atof(value("--camera-yaw"));
+    else if (a == "-p" || a == "--camera-pitch") cameraView[1] = (float)atof(value("--camera-pitch"));
+    else if (a == "--rng") rng = value("--rng");
+    else if (a == "--max-bounces") maxBounces = atoi(value("--max-bounces"));
+    else if (a == "--spheres") nSpheres = atoi(value("--spheres"));
+    else if (a == "--frames") frames = atoi(value("--frames"));
+    else {
+      std::cerr << "ERROR: unrecognised option '" << a << "'" << std::endl << std::endl;
+      usage();
+      return 1;
+    }
+  }
+  int width, height;
+  width = height = size;  // main.cu:66-67
+  std::cout << "cuda-pathtrace 0.3" << std::endl;
+  std::cout << "------------------" << std::endl;
+  std::cout << "Dimensions: " << width << " x " << height << std::endl;
+  std::cout << "Threads per block: " << threadsPerBlock << std::endl;
+  std::cout << "Samples per pixel: " << samplesPerPixel << std::endl;
+  std::cout << "Using CUDA device: " << cudaDevice << std::endl;
+  if (!interactive)
+    std::cout << "Output file prefix: " << outputName << std::endl;
+  else
+    std::cout << "Running in interactive mode: " << (denoising ? "denoising is on" : "denoising is off") << std::endl;
+  std::cout << "Camera: " << cameraPos[0] << " " << cameraPos[1] << " " << cameraPos[2] << " " << cameraView[0] << " "
+            << cameraView[1] << std::endl;
+  if (interactive || denoising) {
+    std::cerr << "ERROR: -i/-d need the OpenGL window / embedded-Python denoiser of the reference, which this build "
+                 "does not include; use --frames N for a headless frame loop" << std::endl;
+    return 1;
+  }
+
+  // set device (main.cu:86)
+  gpuErrchk(pt_set_device(cudaDevice));
+
+  // load scene and create renderer (main.cu:125-128)
+  Scene scene = nSpheres > 0 ? Scene::Random(nSpheres, 1, true) : Scene();
+  pt_renderer_opts opts;
+  pt_renderer_opts_default(&opts);
+  opts.max_bounces = maxBounces;
+  opts.rng_mode = rng == "philox" ? PT_RNG_PHILOX : PT_RNG_XORWOW;
+  Renderer renderer(width, height, samplesPerPixel, threadsPerBlock, opts);
+  Camera camera(cameraPos[0], cameraPos[1], cameraPos[2], cameraView[0], cameraView[1]);
+
+  // allocate output buffer (main.cu:131-139)
+  OutputBuffer d_buffer(width, height);
+  d_buffer.AllocateGPU();
+
+  // render frame(s) (main.cu:182-183; --frames repeats the loop body of main.cu:146-148)
+  float renderTime = 0.0f;
+  for (int f = 0; f < frames; f++) renderTime = renderer.Render(d_buffer, scene, camera);
+  std::cout << "Render completed in " << renderTime << "ms (" << 1000.0f / renderTime << " fps)" << std::endl;
+  std::cout << std::endl;
+  // save results (main.cu:186-192)
+  OutputBuffer buffer(width, height);
+  buffer.AllocateCPU();
+  buffer.CopyFromGPU(d_buffer);
+  buffer.SaveEXR(outputName + ".exr");
+  if (!noBitmap) buffer.SaveBitmaps(outputName);
+  buffer.FreeCPU();
+  d_buffer.FreeGPU();
+  scene.Free();
+  return 0;
+}

@@ -33,3 +33,237 @@ def test_cornell_bit_exact(pt, oracle, gpu, size, spp, rng):
     ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
     assert np.isfinite(img).all()
     assert_bit_exact(img, ref, f"cornell {size}x{size}x{spp} rng={rng}")
+
+
+# ---- committed fixtures: stored vectors, not only the live oracle --------------------------------
+@pytest.mark.parametrize("name", ["oracle_64_spp1_xorwow", "oracle_64_spp4_xorwow", "oracle_64_spp4_philox",
+                                  "oracle_256_spp4_xorwow_rows", "oracle_64_spp16_xorwow_glm_b8"])
+def test_matches_committed_fixture(pt, gpu, name):
+    import os
+
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    size, spp, rng = int(g["size"]), int(g["spp"]), int(g["rng"])
+    mb = 8 if name.endswith("_b8") else 5
+    img, _ = pt.render_frame(size, size, spp, basis=g["basis"], eye=g["eye"], rng_mode=rng, max_bounces=mb)
+    if "image" in g:
+        assert_bit_exact(img, g["image"], name)
+    else:
+        assert_bit_exact(img[g["rows"]], g["row_data"], name)
+
+
+# ---- every kernel variant computes the same bits ---------------------------------------------------
+def _num_variants(pt):
+    n = 0
+    while True:
+        try:
+            pt.Renderer(8, 8, 1, variant=n).destroy()
+            n += 1
+        except pt.PtError:
+            return n
+
+
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_all_variants_bit_exact_vs_oracle(pt, oracle, gpu, rng):
+    basis = pt.camera_basis(width=96, height=96)
+    ref = oracle.render(96, 96, 8, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
+    for v in range(_num_variants(pt)):
+        img, _ = pt.render_frame(96, 96, 8, basis=basis, rng_mode=rng, variant=v)
+        assert_bit_exact(img, ref, f"variant {v} rng {rng}")
+
+
+# ---- multi-GPU tiling: a tile equals the same rows of the full frame --------------------------------
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_row_tiles_equal_full_frame(pt, oracle, gpu, rng):
+    size, spp = 80, 4
+    basis = pt.camera_basis(width=size, height=size)
+    ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
+    for b, e in ((0, 10), (10, 47), (47, 80)):
+        tile, _ = pt.render_frame(size, size, spp, basis=basis, rng_mode=rng, row_begin=b, row_end=e)
+        assert_bit_exact(tile, ref[b:e], f"rows [{b},{e}) rng {rng}")
+
+
+# ---- generator state across frames (Renderer::d_states, pathtrace.cu:212,256) -----------------------
+def test_xorwow_state_persists_across_frames_like_the_reference(pt, oracle, gpu):
+    size, spp = 48, 2
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, spp)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    st = oracle.setup_random(size, size)
+    assert np.array_equal(r.get_rng_state(), st)  # setup_random, pathtrace.cu:259-266
+    for frame in range(3):
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        img = d_out.download(np.float32, (size, size, 14))
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_state=st)
+        assert_bit_exact(img, ref, f"frame {frame}")
+        assert np.array_equal(r.get_rng_state(), st)
+    r.reset_rng()
+    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    first = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis)
+    assert_bit_exact(d_out.download(np.float32, (size, size, 14)), first, "after reset_rng")
+    r.destroy()
+
+
+def test_philox_frames_are_keyed_not_stateful(pt, oracle, gpu):
+    size, spp = 48, 2
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, spp, rng_mode=pt.RNG_PHILOX, seed=0x1234ABCD5678)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    for frame in (0, 1, 2):
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=1,
+                            seed=0x1234ABCD5678, frame=frame)
+        assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, f"philox frame {frame}")
+    r.set_frame(7)
+    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=1, seed=0x1234ABCD5678, frame=7)
+    assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, "philox frame 7")
+    r.destroy()
+
+
+# ---- BASELINE.json configs 4 and 5 at oracle-sized inputs, edge cases ---------------------------------
+@pytest.mark.parametrize("with_walls", [True, False], ids=["closed", "open"])
+def test_thousand_sphere_scene(pt, oracle, gpu, with_walls):
+    """config 4 shape: 1000 random spheres (LDS staging / intersect-loop stress); the open
+    variant makes most paths escape at different depths (divergent early exit)."""
+    sph = pt.scene_random(1000, seed=3, with_walls=with_walls)
+    size, spp = 48, 2
+    basis = pt.camera_basis(width=size, height=size)
+    for v in range(_num_variants(pt)):
+        img, _ = pt.render_frame(size, size, spp, spheres=sph, basis=basis, variant=v)
+        ref = oracle.render(size, size, spp, spheres=sph, basis=basis)
+        assert_bit_exact(img, ref, f"1000 spheres walls={with_walls} variant {v}")
+
+
+def test_interactive_shape_eight_bounces(pt, oracle, gpu):
+    """config 5 shape: 4 spp per frame, 8-bounce cap, several frames into one device buffer."""
+    size = 64
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, 4, max_bounces=8)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    st = oracle.setup_random(size, size)
+    for frame in range(2):
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        ref = oracle.render(size, size, 4, spheres=pt.scene_cornell(), basis=basis, max_bounces=8, rng_state=st)
+        assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, f"8 bounces frame {frame}")
+    r.destroy()
+
+
+def test_edge_cases(pt, oracle, gpu):
+    basis = pt.camera_basis(width=40, height=24)
+    # non-square, ragged last workgroup (40*24 = 960 pixels = 3.75 workgroups)
+    img, _ = pt.render_frame(40, 24, 3, basis=basis)
+    assert_bit_exact(img, oracle.render(40, 24, 3, spheres=pt.scene_cornell(), basis=basis), "40x24")
+    # empty scene: every ray escapes
+    empty = pt.scene_cornell()[:0]
+    img, _ = pt.render_frame(16, 16, 2, spheres=empty, basis=pt.camera_basis(width=16, height=16))
+    assert np.all(img == 0)
+    # max_bounces 0, a single pixel, a single sphere
+    img, _ = pt.render_frame(16, 16, 2, basis=pt.camera_basis(width=16, height=16), max_bounces=0)
+    assert np.all(img == 0)
+    b1 = pt.camera_basis(width=1, height=1)
+    img, _ = pt.render_frame(1, 1, 5, basis=b1)
+    assert_bit_exact(img, oracle.render(1, 1, 5, spheres=pt.scene_cornell(), basis=b1), "1x1")
+    one = pt.scene_cornell()[6:7]
+    b32 = pt.camera_basis(width=32, height=32)
+    img, _ = pt.render_frame(32, 32, 4, spheres=one, basis=b32)
+    assert_bit_exact(img, oracle.render(32, 32, 4, spheres=one, basis=b32), "one sphere")
+    # a zero-row tile is a no-op
+    r = pt.Renderer(32, 32, 1, row_begin=5, row_end=5)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    assert r.render(None, d_scene.ptr, n, b32) == 0.0
+    r.destroy()
+    # too many spheres for the LDS staging budget: loud error, not a silent fallback
+    big = pt.scene_random(4000, seed=1)
+    with pytest.raises(pt.PtError) as e:
+        pt.render_frame(8, 8, 1, spheres=big, basis=pt.camera_basis(width=8, height=8))
+    assert e.value.code == -5
+
+
+# ---- full-size properties at BASELINE.json config 2 (1024 x 1024 x 1024 spp) ----------------------------
+def test_full_size_config2_properties(pt, oracle, gpu):
+    """At the headline size the oracle cannot render the whole frame in seconds, so: (1) three
+    full rows are compared with the oracle bit for bit (3 x 1024 px x 1024 spp = 3.1 Msamples),
+    rendered as 1-row tiles AND cut out of the full frame (tile independence at full size);
+    (2) size-independent properties of the whole frame: finite, closed box => every pixel has a
+    first hit so albedo/normal averages are bounded, variances non-negative."""
+    size, spp = 1024, 1024
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, spp, persist_rng=False)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    ms = r.render(d_out.ptr, d_scene.ptr, n, basis)
+    full = d_out.download(np.float32, (size, size, 14))
+    r.destroy()
+    assert np.isfinite(full).all()
+    assert (full[..., 10:] >= 0).all()
+    nrm = np.linalg.norm(full[..., 3:6], axis=-1)
+    assert (nrm <= 1.0 + 1e-3).all() and (full[..., 9] > 0).all()  # 1024 float32 adds per component
+    assert (full[..., 6:9] >= 0).all() and (full[..., 6:9] <= 1.0).all()
+    for row in (0, 511, 1023):
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, row_begin=row, row_end=row + 1)
+        assert_bit_exact(full[row:row + 1], ref, f"full frame row {row}")
+        tile, _ = pt.render_frame(size, size, spp, basis=basis, row_begin=row, row_end=row + 1, persist_rng=False)
+        assert_bit_exact(tile, ref, f"tile row {row}")
+    print(f"config 2 frame: {ms:.1f} ms, {size * size * spp / ms / 1e3:.0f} Msamples/s")
+
+
+# ---- the C++ look-alike classes + CLI, end to end -------------------------------------------------------
+def _read_feature_exr(path):
+    """Minimal reader for the 14-channel uncompressed scanline EXR the writer emits."""
+    import struct
+
+    raw = open(path, "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01])
+    pos, names, w, h = 8, [], None, None
+    while raw[pos] != 0:
+        e = raw.index(b"\0", pos); name = raw[pos:e].decode(); pos = e + 1
+        e = raw.index(b"\0", pos); typ = raw[pos:e].decode(); pos = e + 1
+        (ln,) = struct.unpack("<I", raw[pos:pos + 4]); pos += 4
+        val = raw[pos:pos + ln]; pos += ln
+        if name == "channels":
+            q = 0
+            while val[q] != 0:
+                e = val.index(b"\0", q); names.append(val[q:e].decode()); q = e + 1 + 16
+        if name == "dataWindow":
+            x0, y0, x1, y1 = struct.unpack("<4i", val); w, h = x1 - x0 + 1, y1 - y0 + 1
+        assert typ
+    pos += 1
+    offs = struct.unpack(f"<{h}Q", raw[pos:pos + 8 * h])
+    planes = np.zeros((len(names), h, w), dtype=np.float32)
+    for y in range(h):
+        o = offs[y] + 8
+        planes[:, y, :] = np.frombuffer(raw[o:o + 4 * w * len(names)], dtype="<f4").reshape(len(names), w)
+    return names, planes
+
+
+def test_cli_front_end_renders_and_saves_like_main_cu(pt, oracle, gpu, tmp_path):
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "cuda-pathtrace_amd", "pathtrace")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = str(tmp_path / "frame")
+    res = subprocess.run([exe, "--size", "64", "-s", "4", "-o", out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "cuda-pathtrace 0.3" in res.stdout and "Render completed in" in res.stdout and "fps)" in res.stdout
+    names, planes = _read_feature_exr(out + ".exr")
+    basis = pt.camera_basis(width=64, height=64)
+    ref = oracle.render(64, 64, 4, spheres=pt.scene_cornell(), basis=basis)
+    src = {"Color.R": 0, "Color.G": 1, "Color.B": 2, "Normal.X": 3, "Normal.Y": 4, "Normal.Z": 5, "Albedo.R": 6,
+           "Albedo.G": 7, "Albedo.B": 8, "Depth.Z": 9, "ColorVar.Z": 10, "NormalVar.Z": 11, "AlbedoVar.Z": 12,
+           "DepthVar.Z": 13}
+    assert len(names) == 14
+    for k, nm in enumerate(names):
+        assert np.array_equal(planes[k].view(np.uint32), ref[..., src[nm]].view(np.uint32)), nm
+    for suffix in ("_color", "_normal", "_albedo", "_depth", "_color_var", "_normal_var", "_albedo_var", "_depth_var"):
+        assert os.path.getsize(out + suffix + ".bmp") == 54 + 64 * 64 * 3
+    # error path: gpuErrchk look-alike prints GPUassert and exits non-zero
+    bad = subprocess.run([exe, "--size", "16", "-s", "1", "--device", "99", "-o", out], capture_output=True, text=True)
+    assert bad.returncode != 0 and "GPUassert:" in bad.stderr
