@@ -7,6 +7,9 @@
 #include "../../include/ptcore.h"
 
 #define PT_BLOCK_THREADS 256
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 1  // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
+#endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it, but we leave room for two resident workgroups).
 #define PT_LDS_BUDGET_BYTES (64 * 1024)

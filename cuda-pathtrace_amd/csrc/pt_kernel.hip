@@ -19,15 +19,31 @@ struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
   float4* mat0;  // {ex, ey, ez, colx}
   float4* mat1;  // {coly, colz, 0, 0}
+  float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds) {
-  SceneLds s{lds, lds + n, lds + 2 * n};
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n};
+  const float qnan = __builtin_nanf("");
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const pt_sphere sp = spheres[i];
-    s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
+    const float rr = sp.radius * sp.radius;
+    s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], rr);
     s.mat0[i] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], sp.color[0]);
     s.mat1[i] = make_float4(sp.color[1], sp.color[2], 0.0f, 0.0f);
+    float* pa = reinterpret_cast<float*>(s.pair + 2 * (i >> 1)) + (i & 1);
+    pa[0] = sp.pos[0];
+    pa[2] = sp.pos[1];
+    pa[4] = sp.pos[2];
+    pa[6] = rr;
+    if ((i == n - 1) && !(i & 1)) {  // odd count: the partner slot is a NaN sphere that can never hit
+      pa[1] = qnan;
+      pa[3] = qnan;
+      pa[5] = qnan;
+      pa[7] = qnan;
+    }
   }
   __syncthreads();
   return s;
@@ -75,13 +91,13 @@ struct Rng<PT_RNG_PHILOX> {
   }
 };
 
-// intersectScene: src/pathtrace.cu:93-107
+// intersectScene: src/pathtrace.cu:93-107 -- literal loop (variants 0 and 1)
 template <int VAR>
-__device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+__device__ __forceinline__ bool intersect_scene_loop(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                     float& t_hit, int& idx) {
   float tNearest = 1000000.0f;
   float t = 0.0f;
   bool hit = false;
-  const RayConst rc = make_ray_const(d);
   for (int i = 0; i < n; i++) {
     const float4 g = sc.geom[i];
     bool h;
@@ -97,6 +113,154 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     }
   }
   return hit;
+}
+
+// Variant 2: screen, then evaluate exactly once.
+//
+// Phase 1 runs the reference's float part of every sphere test (off, b, c, b*b, det: these ARE
+// the contract's values and decide `det >= 0` exactly) and adds a float32 estimate T ~ 2a*t of the
+// root the reference would return, from the cancellation-free forms q = b + sign(b)*s,
+// roots {-q, -(4ac + (b*b - bb))/q}, with s = sqrt(fma(-4a, c, bb)) (one rounding of the
+// contract's exact discriminant, which is built on the ROUNDED product bb = b*b).  For spheres that pass the flags below, |T/(2a*t_exact) - 1| < 2^-21.  The two
+// smallest estimates are kept.
+// Phase 2: if the runner-up is more than 2^-18 (relative) behind, the nearest sphere is decided
+// and only that one runs the FP64 path (bit-identical t).  A lane is "ambiguous" -- and redoes
+// the literal loop over all spheres -- when the two best are closer than that, when a root is
+// too close to zero to classify its sign, when the hit is near the 1e6 acceptance
+// limit (pathtrace.cu:94), or when anything is non-finite.  Ambiguous lanes are rare
+// (box edges, ~1e-5 of rays) and cost only time, never a different result.
+__device__ __forceinline__ bool intersect_scene_screened(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                         float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;  // 1 + 2^-16
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - g.w;
+    const float bb = b * b;
+    const float a4c = rc.a4 * c;
+    const float det = bb - a4c;
+    const float dacc = fmaf(-rc.a4, c, bb);
+    const float s = __builtin_amdgcn_sqrtf(fmaxf(dacc, 0.0f));
+    const float q = b + copysignf(s, b);
+    const float TA = -q;  // = -b - sign(b)*s: the contract's own expression, no cancellation
+    // the other root -b + sign(b)*s = (s*s - b*b)/q, and s*s = bb - 4ac with the ROUNDED bb of the
+    // contract: s*s - b*b = -(4ac + (b*b - bb)); e = b*b - bb is exact in one fma.
+    const float e = fmaf(b, b, -bb);
+    const float num = a4c + e;
+    const float TB = -num * __builtin_amdgcn_rcpf(q);
+    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+    const float T = lo > 0.0f ? lo : hi;
+    const bool real = det >= 0.0f && dacc >= 0.0f;
+    const bool ok = real && T > 0.0f && T < Tlim_hi;
+    // the sign of the cancelling root is the sign of num: reliable unless num is within its own
+    // rounding error (2^-24 |4ac|) of zero; NaN/inf -> unsure
+    unsure = unsure || (real && !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f && fabsf(T) < INF));
+    const float Te = ok ? T : INF;
+    const bool c1 = Te < T1, c2 = Te < T2;
+    T2 = c1 ? T1 : (c2 ? Te : T2);
+    i1 = c1 ? i : i1;
+    T1 = c1 ? Te : T1;
+  }
+  bool ambiguous = unsure || (T1 < INF && (T2 <= T1 * 1.0000038f || T1 >= Tlim * 0.99998f));
+  bool hit = false;
+  if (!ambiguous && T1 < INF) {
+    float t;
+    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+      hit = true;
+      t_hit = t;
+      idx = i1;
+    } else {
+      ambiguous = true;  // the estimate and the exact test disagree: let the literal loop decide
+    }
+  }
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
+// Variant 3: the same screen with the float part evaluated for TWO spheres per instruction
+// (v_pk_add/mul/fma_f32).  A plain FP32 VALU op and an FP64 op both issue at 4 cycles per
+// wave64 on gfx950; only packed FP32 doubles that, and the kernel is VALU-issue bound.  The
+// packed operations are the contract's own mul/add sequence (no contraction), so det, b, c
+// are bit-identical to the scalar path.  Flags are combined without short-circuit branches.
+__device__ __forceinline__ void screen_tail(float b, float a4c, float det, float dacc, float num, float TA, float TB,
+                                            float Tlim_hi, int i, float& T1, float& T2, int& i1, bool& unsure) {
+  const float INF = __builtin_inff();
+  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+  const float T = lo > 0.0f ? lo : hi;
+  const bool real = (det >= 0.0f) & (dacc >= 0.0f);
+  const bool ok = real & (T > 0.0f) & (T < Tlim_hi);
+  unsure = unsure | (real & !((fabsf(num) > fabsf(a4c) * 4.7683716e-07f) & (fabsf(T) < INF)));
+  const float Te = ok ? T : INF;
+  const bool c1 = Te < T1, c2 = Te < T2;
+  T2 = c1 ? T1 : (c2 ? Te : T2);
+  i1 = c1 ? i : i1;
+  T1 = c1 ? Te : T1;
+  (void)b;
+}
+
+__device__ __forceinline__ bool intersect_scene_screened_pk(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                            float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;  // 1 + 2^-16
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+  const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+  const v2f a4 = {rc.a4, rc.a4};
+  const int npairs = (n + 1) >> 1;
+  for (int p = 0; p < npairs; p++) {
+    const float4 A = sc.pair[2 * p], B = sc.pair[2 * p + 1];
+    const v2f offx = ox - v2f{A.x, A.y}, offy = oy - v2f{A.z, A.w}, offz = oz - v2f{B.x, B.y};
+    const v2f dd = dx * offx + dy * offy + dz * offz;
+    const v2f b = dd + dd;
+    const v2f c = (offx * offx + offy * offy + offz * offz) - v2f{B.z, B.w};
+    const v2f bb = b * b;
+    const v2f a4c = a4 * c;
+    const v2f det = bb - a4c;
+    const v2f dacc = __builtin_elementwise_fma(-a4, c, bb);
+    const v2f e = __builtin_elementwise_fma(b, b, -bb);
+    const v2f num = a4c + e;
+    const v2f s = {__builtin_amdgcn_sqrtf(fmaxf(dacc.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(dacc.y, 0.0f))};
+    const v2f q = b + v2f{copysignf(s.x, b.x), copysignf(s.y, b.y)};
+    const v2f r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+    const v2f TA = -q;
+    const v2f TB = -num * r;
+    screen_tail(b.x, a4c.x, det.x, dacc.x, num.x, TA.x, TB.x, Tlim_hi, 2 * p, T1, T2, i1, unsure);
+    screen_tail(b.y, a4c.y, det.y, dacc.y, num.y, TA.y, TB.y, Tlim_hi, 2 * p + 1, T1, T2, i1, unsure);
+  }
+  bool ambiguous = unsure | ((T1 < INF) & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
+  bool hit = false;
+  if (!ambiguous && T1 < INF) {
+    float t;
+    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+      hit = true;
+      t_hit = t;
+      idx = i1;
+    } else {
+      ambiguous = true;
+    }
+  }
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
+template <int VAR>
+__device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+  const RayConst rc = make_ray_const(d);
+  if constexpr (VAR >= 3)
+    return intersect_scene_screened_pk(sc, n, o, d, rc, t_hit, idx);
+  else if constexpr (VAR == 2)
+    return intersect_scene_screened(sc, n, o, d, rc, t_hit, idx);
+  else
+    return intersect_scene_loop<VAR>(sc, n, o, d, rc, t_hit, idx);
 }
 
 // trace_ray: src/pathtrace.cu:150-201
@@ -145,7 +309,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
 
 // pixel_kernel: src/pathtrace.cu:203-257
 template <int RNG, int VAR>
-__global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel(PixelKernelArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
   const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
 
@@ -241,7 +405,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 }  // namespace pt
 
 // ---- launchers (host) ---------------------------------------------------------------------
-static inline size_t scene_lds_bytes(int n) { return (size_t)n * 3 * sizeof(float4); }
+static inline size_t scene_lds_bytes(int n) { return ((size_t)n * 3 + (size_t)((n + 1) / 2) * 2) * sizeof(float4); }
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
@@ -250,11 +414,13 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
   switch (variant) {
     case 0: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 0> : pt::pixel_kernel<PT_RNG_XORWOW, 0>;
     case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
+    case 2: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 2> : pt::pixel_kernel<PT_RNG_XORWOW, 2>;
+    case 3: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 3> : pt::pixel_kernel<PT_RNG_XORWOW, 3>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 2; }
+int pt_kernel_num_variants(void) { return 4; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
@@ -265,7 +431,7 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
 
 int pt_kernel_max_spheres(int variant) {
   (void)variant;
-  return (int)(PT_LDS_BUDGET_BYTES / (3 * sizeof(float4)));
+  return (int)(PT_LDS_BUDGET_BYTES / (4 * sizeof(float4))) - 1;
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
