@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rng", choices=["xorwow", "philox"], default="xorwow")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=None, help="kernel variant (default: the library default)")
     ap.add_argument("--spp", type=int, default=SPP, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~10 s)")
@@ -142,7 +142,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc) and world == 1 and spp == SPP:
             try:
-                traffic = json.load(open(pmc)).get(f"{args.rng}_v{args.variant}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"{args.rng}_v{renderer.variant}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         ki = renderer.kernel_info(len(spheres))
@@ -162,7 +162,7 @@ def main():
             "config": {
                 "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id (BASELINE.json configs[1])",
                 "tiling": f"rows/{world} + gather to rank 0" if world > 1 else "single GPU",
-                "kernel_variant": args.variant,
+                "kernel_variant": renderer.variant,
             },
             "roofline": {
                 "bound": "hbm",

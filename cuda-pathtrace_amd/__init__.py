@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptcore.so")
+# PT_LIB_OVERRIDE: A/B experiments with an alternative build of the same library (tools/ab_tiles.py)
+LIB_PATH = os.environ.get("PT_LIB_OVERRIDE") or os.path.join(_HERE, "libptcore.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 if not os.path.exists(LIB_PATH):
@@ -93,7 +94,13 @@ ABI = {
     "pt_scene_cornell": (ctypes.c_int, [_vp]),
     "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
     "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
+    "pt_debug_unary_map": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
+    "pt_debug_unary_compare": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64,
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
 }
+
+FN_INV_SQRT_LITERAL, FN_INV_SQRT_FAST, FN_SQRT_LITERAL, FN_SQRT_FAST, FN_SIN, FN_COS, FN_UNIFORM = range(7)
+FN_ONEMINUS_LITERAL, FN_ONEMINUS_FAST = 7, 8
 
 lib = ctypes.CDLL(LIB_PATH)
 for _name, (_res, _args) in ABI.items():
@@ -154,6 +161,24 @@ def device_info():
     return {"name": name.value.decode(), "compute_units": cus.value, "clock_khz": khz.value}
 
 
+def unary_map(fn, x):
+    """Evaluate device building block `fn` on a float32 array (on the GPU)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    din, dout = DeviceBuffer(max(x.nbytes, 4)).upload(x), DeviceBuffer(max(x.nbytes, 4))
+    try:
+        check(lib.pt_debug_unary_map(fn, din.ptr, dout.ptr, x.size))
+        return dout.download(np.float32, x.shape)
+    finally:
+        din.free()
+        dout.free()
+
+
+def unary_compare(fn_a, fn_b, first_bits=0, count=1 << 32):
+    n, ex = ctypes.c_uint64(0), ctypes.c_uint32(0)
+    check(lib.pt_debug_unary_compare(fn_a, fn_b, first_bits, count, ctypes.byref(n), ctypes.byref(ex)))
+    return n.value, ex.value
+
+
 class DeviceBuffer:
     """hipMalloc'd bytes (OutputBuffer::AllocateGPU / Scene's sphere upload)."""
 
@@ -196,12 +221,15 @@ class Renderer:
     """ctypes view of pt_renderer (the reference's class Renderer, include/Renderer.h)."""
 
     def __init__(self, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 row_begin=0, row_end=0, persist_rng=True, variant=0):
+                 row_begin=0, row_end=0, persist_rng=True, variant=None):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
         o.row_begin, o.row_end = row_begin, row_end
-        o.persist_rng, o.variant = (1 if persist_rng else 0), variant
+        o.persist_rng = 1 if persist_rng else 0
+        if variant is not None:
+            o.variant = variant
+        self.variant = o.variant
         h = _vp()
         check(lib.pt_renderer_create(width, height, spp, threads_per_block, ctypes.byref(o), ctypes.byref(h)))
         self.handle = h.value

@@ -106,6 +106,7 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
   o->max_bounces = 5;
   o->rng_mode = PT_RNG_XORWOW;
   o->persist_rng = 1;
+  o->variant = PT_DEFAULT_VARIANT;
 }
 
 static int setup_random(pt_renderer* r) {

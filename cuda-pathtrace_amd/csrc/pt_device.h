@@ -174,6 +174,46 @@ __device__ __forceinline__ bool intersect_sphere(F3 o, F3 d, float a, float4 g, 
   return false;
 }
 
+// ---- cheap correctly rounded 1/sqrt and sqrt (float) ------------------------------------------
+// normalize() needs inv = RN(1.0f / RN(sqrtf(x))).  hipcc expands the two correctly rounded
+// operations into ~24 instructions (range scaling, v_sqrt + two residual fixups with selects,
+// v_div_scale/v_rcp/4 fma/v_div_fmas/v_div_fixup).  For x in [2^-100, 2^100] the sequences
+// below give the same bits from 7 (5) instructions: one Newton step on v_rsq_f32's seed with an
+// fma residual lands on the correctly rounded sqrt, and one more lands on the correctly rounded
+// reciprocal of THAT sqrt (except when the sqrt's significand is all ones, handled below).
+// This is not argued, it is CHECKED: tests/test_unary_exhaustive_gpu.py
+// compares them with the literal expressions for every one of the 2^32 float bit patterns on
+// the GPU (0 mismatches), and the literal device expressions with the CPU on a dense sample.
+// Outside the range (zero, denormal, huge, inf, NaN, negative) the literal code runs.
+__device__ __forceinline__ bool in_fast_range(float x) {
+  return ((__float_as_uint(x) >> 23) - 27u) < 200u;  // sign clear and 2^-100 <= x < 2^100
+}
+
+__device__ __forceinline__ float sqrt_cr_f32(float x) {
+  if (__builtin_expect(!in_fast_range(x), 0)) return sqrtf(x);
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y;
+  const float h = 0.5f * y;
+  const float r = fmaf(-s0, s0, x);
+  return fmaf(r, h, s0);
+}
+
+__device__ __forceinline__ float inv_sqrt_spec(float x) {
+  if (__builtin_expect(!in_fast_range(x), 0)) return 1.0f / sqrtf(x);
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y;
+  const float h = 0.5f * y;
+  const float r = fmaf(-s0, s0, x);
+  const float s1 = fmaf(r, h, s0);
+  // 1/s1 for an all-ones significand lies just above a rounding tie that the Newton step
+  // cannot resolve (found by the exhaustive test: exactly these 200 inputs): divide literally.
+  if (__builtin_expect((__float_as_uint(s1) & 0x7FFFFFu) == 0x7FFFFFu, 0)) return 1.0f / s1;
+  const float e = fmaf(-s1, y, 1.0f);
+  return fmaf(e, y, y);
+}
+
+__device__ __forceinline__ F3 normalize_fast(F3 v) { return v * inv_sqrt_spec(dot(v, v)); }
+
 // ---- variant 1: the same values from fewer FP64 instructions -----------------------------------
 // Everything below returns bit-for-bit what intersect_sphere() returns; only the instruction
 // sequence differs.  Per bounce the ray direction is fixed, so den = 2.0*a and an almost
@@ -256,6 +296,22 @@ __device__ __forceinline__ bool intersect_sphere_v1(F3 o, F3 d, const RayConst& 
     return true;
   }
   return false;
+}
+
+// getCosineWeightedNormal with the cheap-but-identical sqrt / 1/sqrt sequences (variants >= 4)
+__device__ __forceinline__ F3 cosine_weighted_fast(F3 dir, float u_az, float u_el) {
+  dir = normalize_fast(dir);
+  F3 o1 = normalize_fast(ortho_vector(dir));
+  F3 o2 = normalize_fast(cross(dir, o1));
+  float rx = u_az * 2.0f * 3.141592654f;
+  float ry = sqrt_cr_f32(u_el);
+  float oneminus = (float)sqrt_cr(1.0 - (double)(ry * ry));
+  float sn, cs;
+  pt_sincos(rx, sn, cs);
+  F3 a = o1 * (cs * oneminus);
+  F3 b = o2 * (sn * oneminus);
+  F3 c = dir * ry;
+  return (a + b) + c;
 }
 
 }  // namespace pt

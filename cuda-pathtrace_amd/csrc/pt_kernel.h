@@ -7,6 +7,16 @@
 #include "../../include/ptcore.h"
 
 #define PT_BLOCK_THREADS 256
+#ifndef PT_SCREEN_UNROLL
+#define PT_SCREEN_UNROLL 9  // unroll factor of the screening loop (ILP at low occupancy)
+#endif
+#define PT_DEFAULT_VARIANT 5  // what pt_renderer_opts_default() selects; 0 is the literal transcription
+#ifndef PT_SCREEN_MAX_SPHERES
+#define PT_SCREEN_MAX_SPHERES 64  // variant 5 screens scenes up to this size, larger ones use the literal loop
+#endif
+#ifndef PT_KERNEL_ATTR
+#define PT_KERNEL_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): let the scheduler spend registers on ILP
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 1  // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
 #endif

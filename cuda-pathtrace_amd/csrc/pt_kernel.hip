@@ -137,6 +137,7 @@ __device__ __forceinline__ bool intersect_scene_screened(const SceneLds& sc, int
   float T1 = INF, T2 = INF;
   int i1 = 0;
   bool unsure = false;
+#pragma unroll PT_SCREEN_UNROLL
   for (int i = 0; i < n; i++) {
     const float4 g = sc.geom[i];
     const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
@@ -252,12 +253,88 @@ __device__ __forceinline__ bool intersect_scene_screened_pk(const SceneLds& sc, 
   return hit;
 }
 
+// Variant 5: the screen of variant 2 as straight-line code (no branches in the loop body, so
+// unrolled iterations interleave) with fewer and cheaper instructions:
+//  * validity (det >= 0, disc >= 0, T > 0) is read off the sign bits: a negative det, dacc or T
+//    puts the candidate's key above every valid key;
+//  * candidates are ranked as unsigned keys = float bits of T with the low ceil(log2 n) bits
+//    replaced by the sphere index, so best / second best are one v_min_u32 + one v_med3_u32.
+//    Truncating T costs 2^-(23-bits) of precision, which the ambiguity margin absorbs.
+// A T of +0, a hit beyond the 1e6 limit or any estimate/exact disagreement is caught by the
+// exact test of phase 2, which sends the lane to the literal loop.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;  // median of three unsigned values in one instruction (no builtin for the integer form)
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                              float& t_hit, int& idx) {
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const uint32_t lim_hi_bits = __float_as_uint(Tlim * 1.0000153f);
+  const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));  // index bits (wave-uniform)
+  const uint32_t imask = (1u << ib) - 1u;
+  const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
+  uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+  bool unsure = false;
+#pragma unroll PT_SCREEN_UNROLL
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - g.w;
+    const float bb = b * b;
+    const float a4c = rc.a4 * c;
+    const float det = bb - a4c;
+    const float dacc = fmaf(-rc.a4, c, bb);
+    const float s = __builtin_amdgcn_sqrtf(dacc);  // NaN for dacc < 0: the sign bit of dacc rejects it below
+    const float q = b + copysignf(s, b);
+    const float e = fmaf(b, b, -bb);
+    const float num = a4c + e;
+    const float TA = -q;
+    const float TB = -num * __builtin_amdgcn_rcpf(q);
+    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+    const float T = lo > 0.0f ? lo : hi;
+    const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
+    const uint32_t w = dd | __float_as_uint(T);
+    uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
+    key = (key & ~imask) | (uint32_t)i;
+    unsure = unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+    k2 = umed3(k1, k2, key);
+    k1 = k1 < key ? k1 : key;
+  }
+  const bool has = k1 < lim_hi_bits;
+  const float T1 = __uint_as_float(k1 & ~imask);
+  bool ambiguous = unsure | (has & (((k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
+  bool hit = false;
+  if (!ambiguous && has) {
+    const int i1 = (int)(k1 & imask);
+    float t;
+    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+      hit = true;
+      t_hit = t;
+      idx = i1;
+    } else {
+      ambiguous = true;
+    }
+  }
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
 template <int VAR>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   const RayConst rc = make_ray_const(d);
-  if constexpr (VAR >= 3)
+  if constexpr (VAR >= 5) {
+    // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
+    // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
+    // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
+    if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys(sc, n, o, d, rc, t_hit, idx);
+    return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  }
+  if constexpr (VAR == 3)
     return intersect_scene_screened_pk(sc, n, o, d, rc, t_hit, idx);
-  else if constexpr (VAR == 2)
+  else if constexpr (VAR == 2 || VAR == 4)
     return intersect_scene_screened(sc, n, o, d, rc, t_hit, idx);
   else
     return intersect_scene_loop<VAR>(sc, n, o, d, rc, t_hit, idx);
@@ -282,7 +359,8 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
     const F3 emis = mk3(m0.x, m0.y, m0.z);
     const F3 scol = mk3(m0.w, m1.x, m1.y);
     F3 pos = o + d * t;                                // :163
-    F3 normal = normalize(pos - mk3(g.x, g.y, g.z));   // :164
+    F3 normal = pos - mk3(g.x, g.y, g.z);              // :164
+    if constexpr (VAR >= 4) normal = normalize_fast(normal); else normal = normalize(normal);
     if (!(dot(normal, d) < 0.0f)) normal = normal * -1.0f;  // :166
     F3 me = mask * emis;
     if (n == 0)  // :171-172
@@ -293,7 +371,10 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
     o = pos + normal * 0.05f;         // :178, PUSH_RAY_ORIGIN
     float u_az, u_el;
     rng.bounce(n, u_az, u_el);
-    d = normalize(cosine_weighted(normal, u_az, u_el));  // :180
+    if constexpr (VAR >= 4)
+      d = normalize_fast(cosine_weighted_fast(normal, u_az, u_el));  // :180
+    else
+      d = normalize(cosine_weighted(normal, u_az, u_el));
     if (n == 0) {                     // :187-195
       L.normal = L.normal + normal;
       L.albedo = L.albedo + scol;
@@ -309,7 +390,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
 
 // pixel_kernel: src/pathtrace.cu:203-257
 template <int RNG, int VAR>
-__global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) pixel_kernel(PixelKernelArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
   const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
 
@@ -416,11 +497,13 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
     case 2: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 2> : pt::pixel_kernel<PT_RNG_XORWOW, 2>;
     case 3: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 3> : pt::pixel_kernel<PT_RNG_XORWOW, 3>;
+    case 4: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 4> : pt::pixel_kernel<PT_RNG_XORWOW, 4>;
+    case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 4; }
+int pt_kernel_num_variants(void) { return 6; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 

@@ -68,7 +68,8 @@ typedef struct pt_renderer_opts {
   int32_t row_end;      /*   rendered by this renderer (multi-GPU row tiling); 0,0 = all   */
   int32_t persist_rng;  /* xorwow only: keep per-pixel generator state across Render()     */
                         /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
-  int32_t variant;      /* kernel variant, 0 = default (see pt_kernel_variants)            */
+  int32_t variant;      /* kernel variant; pt_renderer_opts_default() selects the fastest one,     */
+                        /*   0 = literal transcription; all variants produce identical bits       */
 } pt_renderer_opts;
 
 typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */
@@ -154,6 +155,26 @@ int pt_scene_random(int n, uint64_t seed, int with_walls, pt_sphere* out);
  * restated without glm (float32, same operation order as glm 0.9.8). */
 int pt_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int width, int height,
                     float basis_out[12]);
+
+/* ---- diagnostics (tests only; no reference counterpart) ------------------------------------ */
+/* Scalar building blocks of the device code, evaluated elementwise on the GPU. */
+enum {
+  PT_FN_INV_SQRT_LITERAL = 0, /* 1.0f / sqrtf(x): helper_math normalize's rsqrtf (contract C2) */
+  PT_FN_INV_SQRT_FAST = 1,    /* the 7-instruction sequence the kernel uses for the same value   */
+  PT_FN_SQRT_LITERAL = 2,     /* sqrtf(x)                                                        */
+  PT_FN_SQRT_FAST = 3,        /* 5-instruction correctly rounded sqrt                             */
+  PT_FN_SIN = 4,              /* contract C4 sin on (0, 2*pi]                                     */
+  PT_FN_COS = 5,              /* contract C4 cos                                                  */
+  PT_FN_UNIFORM = 6,          /* curand_uniform mapping of the argument's BIT PATTERN             */
+  PT_FN_ONEMINUS_LITERAL = 7, /* (float)sqrt(1.0 - (double)(x*x)), pathtrace.cu:134               */
+  PT_FN_ONEMINUS_FAST = 8,    /* same through the lean correctly rounded double sqrt              */
+  PT_FN_COUNT = 9
+};
+int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
+/* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits
+ * (count <= 2^32); NaN results compare equal.  *n_mismatch = number of differing inputs. */
+int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
+                           uint32_t* example_bits);
 
 #ifdef __cplusplus
 }

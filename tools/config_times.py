@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Kernel times for the BASELINE.json configs on one GPU, including the row tiles a rank
+renders at N = 2/4/8 GPUs (predicts strong-scaling of the kernel part).  Usage:
+  python tools/config_times.py [variant]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+
+pt = ge.load_package()
+pt.set_device(0)
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+out = {"variant": variant, "device": pt.device_info()}
+
+
+def run(name, size, spp, spheres, reps=3, rows=None, **kw):
+    basis = pt.camera_basis(width=size, height=size)
+    rb, re_ = rows if rows else (0, size)
+    r = pt.Renderer(size, size, spp, variant=variant, row_begin=rb, row_end=re_, **kw)
+    d_scene, n = pt.upload_scene(spheres)
+    d_out = pt.DeviceBuffer((re_ - rb) * size * 14 * 4)
+    ms = [r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(reps)]
+    r.destroy()
+    samples = (re_ - rb) * size * spp
+    res = {"ms_min": round(min(ms), 3), "ms_all": [round(m, 3) for m in ms], "Msamples_per_s": round(samples / min(ms) / 1e3, 1)}
+    out[name] = res
+    print(name, res, flush=True)
+
+
+cornell = pt.scene_cornell()
+run("cfg2_1024x1024x1024spp_full", 1024, 1024, cornell)
+for n in (2, 4, 8):
+    run(f"cfg2_tile_1_of_{n}_rows", 1024, 1024, cornell, rows=(0, 1024 // n))
+run("cfg3_tile_4096x512rows_x64spp (1 of 8)", 4096, 64, cornell, rows=(0, 512))
+run("cfg4_1000spheres_closed_1024x1024x256spp", 1024, 256, pt.scene_random(1000, seed=1, with_walls=True), reps=2)
+run("cfg4_1000spheres_open_1024x1024x256spp", 1024, 256, pt.scene_random(1000, seed=1, with_walls=False), reps=2)
+run("cfg5_512x512x4spp_8bounces_per_frame", 512, 4, cornell, reps=20, max_bounces=8)
+run("cfg5_philox", 512, 4, cornell, reps=20, max_bounces=8, rng_mode=pt.RNG_PHILOX)
+run("cfg1_256x256x4spp", 256, 4, cornell, reps=10)
+json.dump(out, open(os.path.join("gpurun_out", f"config_times_v{variant}.json"), "w"), indent=1)
