@@ -30,15 +30,29 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 BYTES_PER_PIXEL = 56   # 14 x f32 written per pixel per frame
 
 
+def usable_cores():
+    """Threads the CPU baseline may really use: the scheduler affinity mask, capped by the
+    cgroup CPU quota (a GPU box exposes all 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(oracle, spheres, basis, rows):
-    """Oracle (CPU restatement, kind 'port') on all host cores over a bounded sample of the
+    """Oracle (CPU restatement, kind 'port') on the usable host cores over a bounded sample of the
     same workload: a band of `rows` image rows at the full 1024 columns x 1024 spp."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     if rows <= 0:  # size the sample for about 10 s of wall time from a short probe, capped at the full frame
+        probe_rows = 8
         t = time.perf_counter()
-        oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=HEIGHT // 2, row_end=HEIGHT // 2 + 4,
+        oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=HEIGHT // 2, row_end=HEIGHT // 2 + probe_rows,
                       threads=cores)
-        rate = 4 * WIDTH * SPP / (time.perf_counter() - t)
+        rate = probe_rows * WIDTH * SPP / (time.perf_counter() - t)
         rows = int(max(8, min(HEIGHT, 10.0 * rate / (WIDTH * SPP))))
     r0 = HEIGHT // 2 - rows // 2
     t = time.perf_counter()

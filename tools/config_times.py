@@ -41,4 +41,15 @@ run("cfg4_1000spheres_open_1024x1024x256spp", 1024, 256, pt.scene_random(1000, s
 run("cfg5_512x512x4spp_8bounces_per_frame", 512, 4, cornell, reps=20, max_bounces=8)
 run("cfg5_philox", 512, 4, cornell, reps=20, max_bounces=8, rng_mode=pt.RNG_PHILOX)
 run("cfg1_256x256x4spp", 256, 4, cornell, reps=10)
+# PCIe-inclusive single-frame mode (main.cu:187-188): D2H copy of the 58.7 MB buffer into pageable host memory
+import time
+buf = pt.DeviceBuffer(1024 * 1024 * 56)
+host = np.empty(1024 * 1024 * 14, dtype=np.float32)
+ts = []
+for _ in range(5):
+    t = time.perf_counter()
+    pt.check(pt.lib.pt_memcpy_d2h(host.ctypes.data, buf.ptr, host.nbytes))
+    ts.append((time.perf_counter() - t) * 1e3)
+out["d2h_58.7MB_ms"] = [round(x, 3) for x in ts]
+print("d2h 58.7 MB ms", out["d2h_58.7MB_ms"], flush=True)
 json.dump(out, open(os.path.join("gpurun_out", f"config_times_v{variant}.json"), "w"), indent=1)
