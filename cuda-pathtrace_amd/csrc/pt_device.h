@@ -180,12 +180,15 @@ __device__ __forceinline__ bool intersect_sphere(F3 o, F3 d, float a, float4 g, 
 // v_div_scale/v_rcp/4 fma/v_div_fmas/v_div_fixup).  For x in [2^-100, 2^100] the sequences
 // below give the same bits from 7 (5) instructions: one Newton step on v_rsq_f32's seed with an
 // fma residual lands on the correctly rounded sqrt, and one more lands on the correctly rounded
-// reciprocal of THAT sqrt (except when the sqrt's significand is all ones, handled below).
+// reciprocal of THAT sqrt (plus one ulp when the sqrt's significand is all ones, see below).
 // This is not argued, it is CHECKED: tests/test_unary_exhaustive_gpu.py
 // compares them with the literal expressions for every one of the 2^32 float bit patterns on
 // the GPU (0 mismatches), and the literal device expressions with the CPU on a dense sample.
 // Outside the range (zero, denormal, huge, inf, NaN, negative) the literal code runs.
 __device__ __forceinline__ bool in_fast_range(float x) {
+#ifdef PT_TIMING_ONLY_NO_FALLBACKS  // never defined in a shipped build: upper bound of what the rare branches cost
+  return true;
+#endif
   return ((__float_as_uint(x) >> 23) - 27u) < 200u;  // sign clear and 2^-100 <= x < 2^100
 }
 
@@ -205,11 +208,13 @@ __device__ __forceinline__ float inv_sqrt_spec(float x) {
   const float h = 0.5f * y;
   const float r = fmaf(-s0, s0, x);
   const float s1 = fmaf(r, h, s0);
-  // 1/s1 for an all-ones significand lies just above a rounding tie that the Newton step
-  // cannot resolve (found by the exhaustive test: exactly these 200 inputs): divide literally.
-  if (__builtin_expect((__float_as_uint(s1) & 0x7FFFFFu) == 0x7FFFFFu, 0)) return 1.0f / s1;
   const float e = fmaf(-s1, y, 1.0f);
-  return fmaf(e, y, y);
+  const float inv = fmaf(e, y, y);
+  // 1/s1 for an all-ones significand (s1 = 2^k (1 - 2^-24), e.g. the sqrt of the squared length
+  // 1 - 2^-24 of an already normalised vector -- common!) lies just above a rounding tie: the
+  // Newton step returns 2^-k, the correctly rounded value is one ulp up.  Found, and the fix
+  // verified for all 2^32 inputs, by the exhaustive test.
+  return __uint_as_float(__float_as_uint(inv) + (((__float_as_uint(s1) & 0x7FFFFFu) == 0x7FFFFFu) ? 1u : 0u));
 }
 
 __device__ __forceinline__ F3 normalize_fast(F3 v) { return v * inv_sqrt_spec(dot(v, v)); }
@@ -245,7 +250,9 @@ __device__ __forceinline__ RayConst make_ray_const(F3 d) {
 // scaling; anything else (zero, negative, tiny, huge, inf, NaN) takes the library call.
 __device__ __forceinline__ double sqrt_cr(double x) {
   const uint32_t hi = (uint32_t)__double2hiint(x);
+#ifndef PT_TIMING_ONLY_NO_FALLBACKS
   if (__builtin_expect(((hi >> 20) - 423u) >= 1200u, 0)) return sqrt(x);
+#endif
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
   double h = y * 0.5;
@@ -271,7 +278,9 @@ __device__ __forceinline__ float quotient_to_float(double num, const RayConst& r
   const uint32_t lo = (uint32_t)__double2loint(q), hi = (uint32_t)__double2hiint(q);
   const bool near_boundary = ((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u;
   const bool out_of_range = (((hi >> 20) & 0x7FFu) - 903u) >= 247u;
+#ifndef PT_TIMING_ONLY_NO_FALLBACKS
   if (__builtin_expect(near_boundary || out_of_range, 0)) q = num / rc.den;
+#endif
   return (float)q;
 }
 
@@ -296,6 +305,122 @@ __device__ __forceinline__ bool intersect_sphere_v1(F3 o, F3 d, const RayConst& 
     return true;
   }
   return false;
+}
+
+// ---- branch-free forms (variant 6) ------------------------------------------------------------
+// Same sequences, but instead of branching to the literal code on the rare inputs they cannot
+// handle, they OR a flag; the caller redoes the whole step literally when the flag is set.
+// One deferred branch per step instead of ~15 tiny ones per bounce keeps the code straight-line
+// (bigger scheduling regions, fewer scalar branch instructions), which matters most when a
+// small tile leaves only two waves per SIMD.
+__device__ __forceinline__ float sqrt_cr_f32_nb(float x, bool& bad) {
+  bad = bad | !in_fast_range(x);
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y;
+  const float h = 0.5f * y;
+  const float r = fmaf(-s0, s0, x);
+  return fmaf(r, h, s0);
+}
+
+__device__ __forceinline__ float inv_sqrt_spec_nb(float x, bool& bad) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y;
+  const float h = 0.5f * y;
+  const float r = fmaf(-s0, s0, x);
+  const float s1 = fmaf(r, h, s0);
+  bad = bad | !in_fast_range(x);
+  const float e = fmaf(-s1, y, 1.0f);
+  const float inv = fmaf(e, y, y);
+  return __uint_as_float(__float_as_uint(inv) + (((__float_as_uint(s1) & 0x7FFFFFu) == 0x7FFFFFu) ? 1u : 0u));
+}
+
+__device__ __forceinline__ F3 normalize_nb(F3 v, bool& bad) { return v * inv_sqrt_spec_nb(dot(v, v), bad); }
+
+__device__ __forceinline__ double sqrt_cr_nb(double x, bool& bad) {
+  const uint32_t hi = (uint32_t)__double2hiint(x);
+  bad = bad | (((hi >> 20) - 423u) >= 1200u);
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+
+__device__ __forceinline__ float quotient_to_float_nb(double num, const RayConst& rc, bool& bad) {
+  double q = num * rc.rden;
+  double rem = __builtin_fma(-q, rc.den, num);
+  q = __builtin_fma(rem, rc.rden, q);
+  const uint32_t lo = (uint32_t)__double2loint(q), hi = (uint32_t)__double2hiint(q);
+  bad = bad | (((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u) | ((((hi >> 20) & 0x7FFu) - 903u) >= 247u);
+  return (float)q;
+}
+
+// intersect_sphere for a sphere already known to satisfy det >= 0 is NOT assumed: the float part
+// is recomputed and `real` returned exactly as the literal test would.
+__device__ __forceinline__ bool intersect_sphere_nb(F3 o, F3 d, const RayConst& rc, float4 g, float& t, bool& bad) {
+  F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float b = 2.0f * dot(d, off);
+  float c = dot(off, off) - g.w;
+  float bb = b * b;
+  float det = bb - rc.a4 * c;
+  double disc = (double)bb - rc.a4d * (double)c;
+  bool bad_here = false;
+  double sq = sqrt_cr_nb(disc, bad_here);
+  double nb = (double)(-b);
+  float tn = quotient_to_float_nb(nb - sq, rc, bad_here);
+  float tf = quotient_to_float_nb(nb + sq, rc, bad_here);
+  const bool real = det >= 0.0f;
+  bad = bad | (real & bad_here);  // a negative or non-finite disc under det >= 0 lands here too
+  t = (tn > 0.0f && tf > 0.0f) ? fminf(tn, tf) : (tn > 0.0f ? tn : tf);
+  return real;
+}
+
+// the geometric part of one bounce: src/pathtrace.cu:163-166,178-180
+struct BounceGeom {
+  F3 normal;  // flipped shading normal
+  F3 o, d;    // next ray
+};
+
+template <bool FAST>
+__device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 centre, float u_az, float u_el, bool& bad) {
+  BounceGeom out;
+  F3 pos = o + d * t;
+  F3 normal = pos - centre;
+  if constexpr (FAST) normal = normalize_nb(normal, bad); else normal = normalize(normal);
+  if (!(dot(normal, d) < 0.0f)) normal = normal * -1.0f;
+  out.normal = normal;
+  out.o = pos + normal * 0.05f;
+  // getCosineWeightedNormal, :126-136
+  F3 dir, o1, o2;
+  float ry, oneminus;
+  if constexpr (FAST) {
+    dir = normalize_nb(normal, bad);
+    o1 = normalize_nb(ortho_vector(dir), bad);
+    o2 = normalize_nb(cross(dir, o1), bad);
+    ry = sqrt_cr_f32_nb(u_el, bad);
+    oneminus = (float)sqrt_cr_nb(1.0 - (double)(ry * ry), bad);
+  } else {
+    dir = normalize(normal);
+    o1 = normalize(ortho_vector(dir));
+    o2 = normalize(cross(dir, o1));
+    ry = sqrtf(u_el);
+    oneminus = (float)sqrt(1.0 - (double)(ry * ry));
+  }
+  float rx = u_az * 2.0f * 3.141592654f;
+  float sn, cs;
+  pt_sincos(rx, sn, cs);
+  F3 a = o1 * (cs * oneminus);
+  F3 b = o2 * (sn * oneminus);
+  F3 c = dir * ry;
+  F3 nd = (a + b) + c;
+  if constexpr (FAST) out.d = normalize_nb(nd, bad); else out.d = normalize(nd);
+  return out;
 }
 
 // getCosineWeightedNormal with the cheap-but-identical sqrt / 1/sqrt sequences (variants >= 4)

@@ -10,7 +10,7 @@
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // unroll factor of the screening loop (ILP at low occupancy)
 #endif
-#define PT_DEFAULT_VARIANT 5  // what pt_renderer_opts_default() selects; 0 is the literal transcription
+#define PT_DEFAULT_VARIANT 6  // what pt_renderer_opts_default() selects; 0 is the literal transcription
 #ifndef PT_SCREEN_MAX_SPHERES
 #define PT_SCREEN_MAX_SPHERES 64  // variant 5 screens scenes up to this size, larger ones use the literal loop
 #endif

@@ -12,6 +12,9 @@
 
 namespace pt {
 
+#define PT_PRAGMA_(x) _Pragma(#x)
+#define PT_UNROLL(n) PT_PRAGMA_(unroll n)
+
 // LDS image of the scene: geometry and material split so the intersect loop touches
 // 16 B per sphere with a wave-uniform address (LDS broadcast read), and the shading step
 // gathers 32 B by the per-lane hit index.
@@ -137,7 +140,7 @@ __device__ __forceinline__ bool intersect_scene_screened(const SceneLds& sc, int
   float T1 = INF, T2 = INF;
   int i1 = 0;
   bool unsure = false;
-#pragma unroll PT_SCREEN_UNROLL
+PT_UNROLL(PT_SCREEN_UNROLL)
   for (int i = 0; i < n; i++) {
     const float4 g = sc.geom[i];
     const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
@@ -268,8 +271,10 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
   return r;
 }
 
+template <bool NB>
 __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                               float& t_hit, int& idx) {
+  if (n <= 0) return false;
   const float Tlim = 1000000.0f * (2.0f * rc.a);
   const uint32_t lim_hi_bits = __float_as_uint(Tlim * 1.0000153f);
   const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));  // index bits (wave-uniform)
@@ -277,9 +282,7 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
   uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
   bool unsure = false;
-#pragma unroll PT_SCREEN_UNROLL
-  for (int i = 0; i < n; i++) {
-    const float4 g = sc.geom[i];
+  auto screen = [&](const float4 g, int i) {
     const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
     const float b = 2.0f * dot(d, off);
     const float c = dot(off, off) - g.w;
@@ -302,24 +305,52 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
     unsure = unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
     k2 = umed3(k1, k2, key);
     k1 = k1 < key ? k1 : key;
+  };
+  // Manually unrolled by three (hipcc does not runtime-unroll this loop on request): the three
+  // LDS reads are issued together and the three dependency chains interleave, which is what
+  // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
+  int i = 0;
+  for (; i + 3 <= n; i += 3) {
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2];
+    screen(g0, i);
+    screen(g1, i + 1);
+    screen(g2, i + 2);
   }
+  for (; i < n; i++) screen(sc.geom[i], i);
   const bool has = k1 < lim_hi_bits;
   const float T1 = __uint_as_float(k1 & ~imask);
   bool ambiguous = unsure | (has & (((k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
   bool hit = false;
-  if (!ambiguous && has) {
+  if constexpr (NB) {
+    // straight-line: evaluate the winner unconditionally, decide afterwards
     const int i1 = (int)(k1 & imask);
     float t;
-    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
-      hit = true;
-      t_hit = t;
-      idx = i1;
-    } else {
-      ambiguous = true;
+    bool bad = false;
+    const bool real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
+    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    ambiguous = ambiguous | (has & (bad | !good));
+    hit = has & good;
+    t_hit = t;
+    idx = i1;
+#ifndef PT_TIMING_ONLY_NO_ISECT_REDO
+    if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+#endif
+    return hit;
+  } else {
+    if (!ambiguous && has) {
+      const int i1 = (int)(k1 & imask);
+      float t;
+      if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+        hit = true;
+        t_hit = t;
+        idx = i1;
+      } else {
+        ambiguous = true;
+      }
     }
+    if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+    return hit;
   }
-  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
-  return hit;
 }
 
 template <int VAR>
@@ -329,7 +360,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
-    if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys(sc, n, o, d, rc, t_hit, idx);
+    if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }
   if constexpr (VAR == 3)
@@ -358,23 +389,38 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
     const float4 m1 = sc.mat1[idx];
     const F3 emis = mk3(m0.x, m0.y, m0.z);
     const F3 scol = mk3(m0.w, m1.x, m1.y);
+    F3 normal;
+    float u_az, u_el;
+    if constexpr (VAR >= 6) {
+      // whole geometric step speculatively with the cheap sequences, literal redo if any of them
+      // met an input outside its verified domain (never observed in the Cornell box)
+      rng.bounce(n, u_az, u_el);
+      bool bad = false;
+      BounceGeom bg = bounce_geometry<true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+#ifndef PT_TIMING_ONLY_NO_SHADE_REDO
+      if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+#endif
+      normal = bg.normal;
+      o = bg.o;
+      d = bg.d;
+    } else {
     F3 pos = o + d * t;                                // :163
-    F3 normal = pos - mk3(g.x, g.y, g.z);              // :164
+    normal = pos - mk3(g.x, g.y, g.z);                 // :164
     if constexpr (VAR >= 4) normal = normalize_fast(normal); else normal = normalize(normal);
     if (!(dot(normal, d) < 0.0f)) normal = normal * -1.0f;  // :166
+    o = pos + normal * 0.05f;         // :178, PUSH_RAY_ORIGIN
+    rng.bounce(n, u_az, u_el);
+    if constexpr (VAR >= 4)
+      d = normalize_fast(cosine_weighted_fast(normal, u_az, u_el));  // :180
+    else
+      d = normalize(cosine_weighted(normal, u_az, u_el));
+    }
     F3 me = mask * emis;
     if (n == 0)  // :171-172
       color = color + mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f));
     else  // :174
       color = color + me;
     mask = mask * scol;               // :175
-    o = pos + normal * 0.05f;         // :178, PUSH_RAY_ORIGIN
-    float u_az, u_el;
-    rng.bounce(n, u_az, u_el);
-    if constexpr (VAR >= 4)
-      d = normalize_fast(cosine_weighted_fast(normal, u_az, u_el));  // :180
-    else
-      d = normalize(cosine_weighted(normal, u_az, u_el));
     if (n == 0) {                     // :187-195
       L.normal = L.normal + normal;
       L.albedo = L.albedo + scol;
@@ -499,11 +545,12 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 3: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 3> : pt::pixel_kernel<PT_RNG_XORWOW, 3>;
     case 4: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 4> : pt::pixel_kernel<PT_RNG_XORWOW, 4>;
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
+    case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 6; }
+int pt_kernel_num_variants(void) { return 7; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
