@@ -353,6 +353,59 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   }
 }
 
+// Many-sphere scenes (BASELINE config 4): most spheres are missed by every lane of the wave, so the
+// screen first runs only the contract's float part and skips the rest of the iteration with one
+// wave-uniform branch when no lane has a real intersection.  Candidates keep full float precision
+// (index tracked separately), the winner alone runs the FP64 path.
+__device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                               float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - g.w;
+    const float bb = b * b;
+    const float a4c = rc.a4 * c;
+    const float det = bb - a4c;
+    const float dacc = fmaf(-rc.a4, c, bb);
+    const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
+    if (__builtin_amdgcn_ballot_w64((int)dd >= 0) == 0) continue;  // nobody in the wave hits this sphere
+    const float s = __builtin_amdgcn_sqrtf(dacc);
+    const float q = b + copysignf(s, b);
+    const float e = fmaf(b, b, -bb);
+    const float num = a4c + e;
+    const float TA = -q;
+    const float TB = -num * __builtin_amdgcn_rcpf(q);
+    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+    const float T = lo > 0.0f ? lo : hi;
+    const bool ok = ((int)(dd | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
+    unsure = unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+    const float Te = ok ? T : INF;
+    const bool c1 = Te < T1, c2 = Te < T2;
+    T2 = c1 ? T1 : (c2 ? Te : T2);
+    i1 = c1 ? i : i1;
+    T1 = c1 ? Te : T1;
+  }
+  const bool has = T1 < INF;
+  bool ambiguous = unsure | (has & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
+  float t;
+  bool bad = false;
+  const bool real = intersect_sphere_nb(o, d, rc, sc.geom[i1], t, bad);
+  const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+  ambiguous = ambiguous | (has & (bad | !good));
+  t_hit = t;
+  idx = i1;
+  bool hit = has & good;
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
 template <int VAR>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   const RayConst rc = make_ray_const(d);
@@ -361,6 +414,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
     if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+    if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }
   if constexpr (VAR == 3)
@@ -434,6 +488,187 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
   welford_update(var[0], luminance(color));     // :200
 }
 
+// ---- variant 7: two samples of a pixel in lockstep ---------------------------------------------
+// A lane traces samples 2k and 2k+1 together, so every stage has two independent dependency
+// chains to interleave: what a small row tile (multi-GPU, ~2 waves per SIMD) needs, since there
+// a lone wave is latency-bound.  Sample order is part of the contract (sequential generator,
+// sequential float sums and Welford updates), so:
+//  * xorwow: sample B's generator is A's advanced by the 2 + 2*max_bounces draws a non-escaping
+//    path consumes (speculation).  If A escapes early the speculation was wrong and B is retraced
+//    alone from A's true final state -- never in a closed scene, at worst 1.5x work in an open one;
+//  * philox is counter-based: no speculation;
+//  * results are accumulated strictly A then B, with the reference's own expressions.
+struct PathResult {
+  F3 color, normal0, albedo0;
+  float t0;
+  bool hit0;     // the primary ray hit something: first-bounce features exist (:187-195)
+  bool escaped;  // the path left the scene: no colour-variance update (:157-161)
+};
+
+struct ScreenState {
+  uint32_t k1, k2;
+  bool unsure;
+};
+
+__device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
+                                              ScreenState& st) {
+  const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  const float b = 2.0f * dot(d, off);
+  const float c = dot(off, off) - g.w;
+  const float bb = b * b;
+  const float a4c = rc.a4 * c;
+  const float det = bb - a4c;
+  const float dacc = fmaf(-rc.a4, c, bb);
+  const float s = __builtin_amdgcn_sqrtf(dacc);
+  const float q = b + copysignf(s, b);
+  const float e = fmaf(b, b, -bb);
+  const float num = a4c + e;
+  const float TA = -q;
+  const float TB = -num * __builtin_amdgcn_rcpf(q);
+  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+  const float T = lo > 0.0f ? lo : hi;
+  const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
+  const uint32_t w = dd | __float_as_uint(T);
+  uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
+  key = (key & ~imask) | (uint32_t)i;
+  st.unsure = st.unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+  st.k2 = umed3(st.k1, st.k2, key);
+  st.k1 = st.k1 < key ? st.k1 : key;
+}
+
+// nearest hit for P rays at once; same decisions as intersect_scene_screened_keys<true>
+template <int P>
+__device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const F3 (&o)[P], const F3 (&d)[P],
+                                                bool (&hit)[P], float (&t_hit)[P], int (&idx)[P]) {
+  RayConst rc[P];
+  ScreenState st[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    rc[p] = make_ray_const(d[p]);
+    st[p] = ScreenState{0xFFFFFFFFu, 0xFFFFFFFFu, false};
+    hit[p] = false;
+  }
+  if (n <= 0) return;
+  if (n > PT_SCREEN_MAX_SPHERES) {
+#pragma unroll
+    for (int p = 0; p < P; p++) hit[p] = intersect_scene_loop<1>(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
+    return;
+  }
+  const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));
+  const uint32_t imask = (1u << ib) - 1u;
+  const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);
+  int i = 0;
+  for (; i + 2 <= n; i += 2) {
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      screen_sphere(g0, i, o[p], d[p], rc[p], imask, st[p]);
+      screen_sphere(g1, i + 1, o[p], d[p], rc[p], imask, st[p]);
+    }
+  }
+  for (; i < n; i++) {
+    const float4 g = sc.geom[i];
+#pragma unroll
+    for (int p = 0; p < P; p++) screen_sphere(g, i, o[p], d[p], rc[p], imask, st[p]);
+  }
+  bool ambiguous[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    const float Tlim = 1000000.0f * (2.0f * rc[p].a);
+    const bool has = st[p].k1 < __float_as_uint(Tlim * 1.0000153f);
+    const float T1 = __uint_as_float(st[p].k1 & ~imask);
+    ambiguous[p] = st[p].unsure | (has & (((st[p].k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
+    const int i1 = (int)(st[p].k1 & imask);
+    float t;
+    bool bad = false;
+    const bool real = intersect_sphere_nb(o[p], d[p], rc[p], sc.geom[has ? i1 : 0], t, bad);
+    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    ambiguous[p] = ambiguous[p] | (has & (bad | !good));
+    hit[p] = has & good;
+    t_hit[p] = t;
+    idx[p] = i1;
+  }
+#pragma unroll
+  for (int p = 0; p < P; p++)
+    if (__builtin_expect(ambiguous[p], 0)) hit[p] = intersect_scene_loop<0>(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
+}
+
+// trace_ray (src/pathtrace.cu:150-201) for P paths in lockstep; results are returned, not accumulated
+template <int RNG, int P>
+__device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds& sc, int nsph, F3 (&o)[P], F3 (&d)[P],
+                                            Rng<RNG> (&rng)[P], int max_bounces) {
+  F3 color[P], mask[P];
+  bool alive[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    color[p] = mk3(0.0f, 0.0f, 0.0f);
+    mask[p] = mk3(1.0f, 1.0f, 1.0f);
+    alive[p] = true;
+    res[p].hit0 = false;
+    res[p].escaped = false;
+    res[p].normal0 = mk3(0.0f, 0.0f, 0.0f);
+    res[p].albedo0 = mk3(0.0f, 0.0f, 0.0f);
+    res[p].t0 = 0.0f;
+  }
+  for (int n = 0; n < max_bounces; n++) {
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < P; p++) any = any | alive[p];
+    if (!any) break;
+    bool hit[P];
+    float t[P];
+    int idx[P];
+    intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const bool was_alive = alive[p];
+      res[p].escaped = res[p].escaped | (was_alive & !hit[p]);  // :157-161
+      alive[p] = was_alive & hit[p];
+      const int ix = alive[p] ? idx[p] : 0;
+      const float4 g = sc.geom[ix];
+      const float4 m0 = sc.mat0[ix];
+      const float4 m1 = sc.mat1[ix];
+      const F3 emis = mk3(m0.x, m0.y, m0.z);
+      const F3 scol = mk3(m0.w, m1.x, m1.y);
+      float u_az = 0.5f, u_el = 0.5f;
+      if (alive[p]) rng[p].bounce(n, u_az, u_el);  // a dead path draws nothing
+      bool bad = false;
+      BounceGeom bg = bounce_geometry<true>(o[p], d[p], t[p], mk3(g.x, g.y, g.z), u_az, u_el, bad);
+      if (__builtin_expect(bad & alive[p], 0)) bg = bounce_geometry<false>(o[p], d[p], t[p], mk3(g.x, g.y, g.z), u_az, u_el, bad);
+      const F3 me = mask[p] * emis;
+      const F3 add = (n == 0) ? mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f)) : me;  // :171-174
+      if (alive[p]) {
+        color[p] = color[p] + add;
+        mask[p] = mask[p] * scol;  // :175
+        o[p] = bg.o;
+        d[p] = bg.d;
+        if (n == 0) {  // :187-195 (accumulated by the caller)
+          res[p].hit0 = true;
+          res[p].normal0 = bg.normal;
+          res[p].albedo0 = scol;
+          res[p].t0 = t[p];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; p++) res[p].color = color[p];
+}
+
+// what trace_ray adds to the pixel's accumulators for one finished path, in the reference's order
+__device__ __forceinline__ void accumulate_path(TraceOutput& L, Welford (&var)[4], const PathResult& r) {
+  if (r.hit0) {  // :187-195
+    L.normal = L.normal + r.normal0;
+    L.albedo = L.albedo + r.albedo0;
+    L.depth += r.t0;
+    welford_update(var[1], luminance(r.normal0));
+    welford_update(var[2], luminance(r.albedo0));
+    welford_update(var[3], r.t0);
+  }
+  L.color = L.color + r.color;                                   // :159 / :198
+  if (!r.escaped) welford_update(var[0], luminance(r.color));    // :200
+}
+
 // pixel_kernel: src/pathtrace.cu:203-257
 template <int RNG, int VAR>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
@@ -467,19 +702,53 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
   TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
 
-  for (int i = 0; i < a.spp; i++) {  // :219
-    rng.begin_sample((uint32_t)i);
-    float sx = (float)row, sy = (float)col;  // :221
-    if (a.spp != 1) {                        // :222-225
+  auto primary_ray = [&](Rng<RNG>& g, F3& dir) {  // :221-229
+    float sx = (float)row, sy = (float)col;
+    if (a.spp != 1) {
       float jx, jy;
-      rng.jitter(jx, jy);
+      g.jitter(jx, jy);
       sx += jx * 1.0f - 0.5f;
       sy += jy * 1.0f - 0.5f;
     }
-    sx /= (float)a.height;  // :226 (contract C7)
+    sx /= (float)a.height;  // contract C7
     sy /= (float)a.width;
-    F3 dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);  // :229
-    trace_ray<RNG, VAR>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+    dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
+  };
+
+  int i = 0;
+  if constexpr (VAR >= 7) {
+    const int draws = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;  // consumed by a path that never escapes
+    for (; i + 2 <= a.spp; i += 2) {
+      Rng<RNG> g[2] = {rng, rng};
+      g[0].begin_sample((uint32_t)i);
+      if constexpr (RNG == PT_RNG_XORWOW) {
+        for (int k = 0; k < draws; k++) (void)xorwow_next(g[1].st);
+      }
+      g[1].begin_sample((uint32_t)i + 1u);
+      F3 o2[2] = {eye, eye}, d2[2];
+      primary_ray(g[0], d2[0]);
+      primary_ray(g[1], d2[1]);
+      PathResult res[2];
+      trace_paths<RNG, 2>(res, sc, a.n_spheres, o2, d2, g, a.max_bounces);
+      accumulate_path(L, var, res[0]);
+      if (RNG == PT_RNG_XORWOW && __builtin_expect(res[0].escaped, 0)) {
+        // A consumed fewer draws than assumed: B's stream was wrong, retrace it from A's true state
+        rng = g[0];
+        rng.begin_sample((uint32_t)i + 1u);
+        F3 dir;
+        primary_ray(rng, dir);
+        trace_ray<RNG, 6>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);
+      } else {
+        accumulate_path(L, var, res[1]);
+        rng = g[1];
+      }
+    }
+  }
+  for (; i < a.spp; i++) {  // :219
+    rng.begin_sample((uint32_t)i);
+    F3 dir;
+    primary_ray(rng, dir);
+    trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
   }
 
   const float fs = (float)a.spp;  // :234-237
@@ -546,11 +815,12 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 4: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 4> : pt::pixel_kernel<PT_RNG_XORWOW, 4>;
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
     case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
+    case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 7; }
+int pt_kernel_num_variants(void) { return 8; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
