@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~10 s)")
+    ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame to this .npy (tests)")
     args = ap.parse_args()
 
     import torch
@@ -98,12 +99,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    pt.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PT_BENCH_SHARED_GPU=1 + PT_BENCH_BACKEND=gloo: functional test of the multi-rank path with all
+    # ranks on GPU 0 (tests/test_bench_multirank_gpu.py); the driver's runs use one GPU per rank + RCCL
+    dev_index = 0 if os.environ.get("PT_BENCH_SHARED_GPU") == "1" else local_rank
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    pt.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     spp = args.spp
     rng_mode = pt.RNG_PHILOX if args.rng == "philox" else pt.RNG_XORWOW
@@ -147,6 +155,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_s = tmax[0].item(), tmax[1].item()
 
+    if rank == 0 and args.dump:
+        import numpy as np
+
+        np.save(args.dump, fg.frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
     if rank == 0:
         total_samples = WIDTH * HEIGHT * spp * args.steps
         ms_per_step = elapsed / args.steps * 1e3
@@ -175,7 +187,7 @@ def main():
             "data": "synthetic (reference scene include/Scene.h:26-34, default camera, fixed seed)",
             "config": {
                 "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id (BASELINE.json configs[1])",
-                "tiling": f"rows/{world} + gather to rank 0" if world > 1 else "single GPU",
+                "tiling": f"rows/{world} + gather to rank 0 ({backend})" if world > 1 else "single GPU",
                 "kernel_variant": renderer.variant,
             },
             "roofline": {

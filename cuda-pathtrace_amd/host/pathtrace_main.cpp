@@ -4,12 +4,19 @@
 // Same flags, defaults, banner and timing line; -i/-d (OpenGL window, embedded-Python CNN
 // denoiser) are accepted and reported as unsupported: both are out of scope.
 // Additions: --rng, --max-bounces, --spheres N (seeded random scene), --frames N (headless
-// stand-in for the interactive loop main.cu:146-177: N x Render() into the same device buffer).
+// stand-in for the interactive loop main.cu:146-177: N x Render() into the same device buffer),
+// --poses FILE (scripted fly-through: one "x y z yaw pitch" line per frame, the pose-list format of
+// collect_data.py:20-31; generator state carries over from frame to frame like the reference's
+// interactive mode, per-frame times are summarised).
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
+#include <vector>
 
 #include "Camera.h"
 #include "OutputBuffer.h"
@@ -37,6 +44,7 @@ static void usage() {
                "  --max-bounces arg             path length cap (default 5)\n"
                "  --spheres arg                 render a seeded random scene of N spheres\n"
                "  --frames arg                  render N frames back to back (headless interactive loop)\n"
+               "  --poses arg                   fly-through: file with one 'x y z yaw pitch' line per frame\n"
             << std::endl;
 }
 
@@ -52,6 +60,7 @@ int main(int argc, const char** argv) {
   std::string outputName = "output/out";
   std::string rng = "xorwow";
   int maxBounces = 5, nSpheres = 0, frames = 1;
+  std::string posesFile;
 
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -81,6 +90,7 @@ int main(int argc, const char** argv) {
     else if (a == "--max-bounces") maxBounces = atoi(value("--max-bounces"));
     else if (a == "--spheres") nSpheres = atoi(value("--spheres"));
     else if (a == "--frames") frames = atoi(value("--frames"));
+    else if (a == "--poses") posesFile = value("--poses");
     else {
       std::cerr << "ERROR: unrecognised option '" << a << "'" << std::endl << std::endl;
       usage();
@@ -125,7 +135,38 @@ int main(int argc, const char** argv) {
 
   // render frame(s) (main.cu:182-183; --frames repeats the loop body of main.cu:146-148)
   float renderTime = 0.0f;
-  for (int f = 0; f < frames; f++) renderTime = renderer.Render(d_buffer, scene, camera);
+  if (!posesFile.empty()) {
+    // headless version of the interactive loop: the camera moves, the same device buffer and the
+    // same renderer (generator state included) are reused every frame (main.cu:146-148)
+    std::ifstream in(posesFile.c_str());
+    if (!in) {
+      std::cerr << "ERROR: cannot open pose file " << posesFile << std::endl;
+      return 1;
+    }
+    std::vector<float> times;
+    std::string line;
+    while (std::getline(in, line)) {
+      std::istringstream ls(line);
+      float x, y, z, yaw, pitch;
+      if (!(ls >> x >> y >> z >> yaw >> pitch)) continue;
+      Camera pose(x, y, z, yaw, pitch);
+      renderTime = renderer.Render(d_buffer, scene, pose);
+      times.push_back(renderTime);
+    }
+    if (times.empty()) {
+      std::cerr << "ERROR: no poses in " << posesFile << std::endl;
+      return 1;
+    }
+    std::vector<float> sorted(times);
+    std::sort(sorted.begin(), sorted.end());
+    double sum = 0;
+    for (float t : times) sum += t;
+    std::cout << "Fly-through: " << times.size() << " frames, mean " << sum / times.size() << "ms, median "
+              << sorted[sorted.size() / 2] << "ms, min " << sorted.front() << "ms, max " << sorted.back() << "ms ("
+              << 1000.0 * times.size() / sum << " fps)" << std::endl;
+  } else {
+    for (int f = 0; f < frames; f++) renderTime = renderer.Render(d_buffer, scene, camera);
+  }
   std::cout << "Render completed in " << renderTime << "ms (" << 1000.0f / renderTime << " fps)" << std::endl;
   std::cout << std::endl;
   // save results (main.cu:186-192)

@@ -33,6 +33,10 @@ class FrameGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows = row_range(height, self.world, self.rank)
         self.is_root = self.rank == dst
+        # gloo cannot send/recv device tensors: stage through the host (functional testing of the
+        # multi-rank path on a box without RCCL peers; the production backend is "nccl" = RCCL)
+        self.stage_host = (dist.is_initialized() and dist.get_backend(group) == "gloo"
+                           and torch.device(device).type == "cuda")
         rf = width * CHANNELS
         if self.is_root:
             self.frame = torch.empty(height * rf, dtype=torch.float32, device=device)
@@ -47,6 +51,17 @@ class FrameGather:
         if self.world == 1:
             return []
         rf = self.width * CHANNELS
+        if self.stage_host:
+            if self.is_root:
+                for r in range(self.world):
+                    b, e = row_range(self.height, self.world, r)
+                    if r != self.rank and e > b:
+                        buf = torch.empty((e - b) * rf, dtype=torch.float32)
+                        dist.recv(buf, src=r, group=self.group)
+                        self.frame[b * rf : e * rf].copy_(buf)
+            elif self.tile.numel():
+                dist.send(self.tile.cpu(), dst=self.dst, group=self.group)
+            return []
         ops = []
         if self.is_root:
             for r in range(self.world):

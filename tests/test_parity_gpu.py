@@ -65,12 +65,17 @@ def _num_variants(pt):
 
 
 @pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
-def test_all_variants_bit_exact_vs_oracle(pt, oracle, gpu, rng):
+@pytest.mark.parametrize("spp", [1, 5, 8])
+def test_all_variants_bit_exact_vs_oracle(pt, oracle, gpu, rng, spp):
+    """Every kernel variant, even / odd / single sample counts (variant 7 pairs samples), on the
+    closed box and on an open scene where paths escape at different depths (variant 7 then has to
+    retrace the second sample of a pair from the first one's true generator state)."""
     basis = pt.camera_basis(width=96, height=96)
-    ref = oracle.render(96, 96, 8, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
-    for v in range(_num_variants(pt)):
-        img, _ = pt.render_frame(96, 96, 8, basis=basis, rng_mode=rng, variant=v)
-        assert_bit_exact(img, ref, f"variant {v} rng {rng}")
+    for name, sph in (("cornell", pt.scene_cornell()), ("open", pt.scene_cornell()[[0, 2, 4, 6, 7, 8]])):
+        ref = oracle.render(96, 96, spp, spheres=sph, basis=basis, rng_mode=rng)
+        for v in range(_num_variants(pt)):
+            img, _ = pt.render_frame(96, 96, spp, spheres=sph, basis=basis, rng_mode=rng, variant=v)
+            assert_bit_exact(img, ref, f"{name} variant {v} rng {rng} spp {spp}")
 
 
 # ---- multi-GPU tiling: a tile equals the same rows of the full frame --------------------------------
@@ -267,3 +272,31 @@ def test_cli_front_end_renders_and_saves_like_main_cu(pt, oracle, gpu, tmp_path)
     # error path: gpuErrchk look-alike prints GPUassert and exits non-zero
     bad = subprocess.run([exe, "--size", "16", "-s", "1", "--device", "99", "-o", out], capture_output=True, text=True)
     assert bad.returncode != 0 and "GPUassert:" in bad.stderr
+
+
+def test_cli_fly_through_matches_frame_by_frame_oracle(pt, oracle, gpu, tmp_path):
+    """--poses: the headless interactive loop (main.cu:146-148): camera moves every frame, renderer
+    and generator state persist.  The saved last frame must equal the oracle driven the same way."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    poses = [(50.0, 52.0, 295.6, -90.0, 0.0), (48.0, 50.0, 280.0, -88.0, -2.0), (55.0, 45.0, 250.0, -95.0, 3.0)]
+    pf = tmp_path / "poses.txt"
+    pf.write_text("".join("%g %g %g %g %g\n" % p for p in poses))
+    out = str(tmp_path / "fly")
+    exe = os.path.join(ROOT, "cuda-pathtrace_amd", "pathtrace")
+    res = subprocess.run([exe, "--size", "64", "-s", "4", "--max-bounces", "8", "--poses", str(pf), "--nobitmap", "-o", out],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "Fly-through: 3 frames" in res.stdout
+    st = oracle.setup_random(64, 64)
+    for x, y, z, yaw, pitch in poses:
+        basis = pt.camera_basis((x, y, z), yaw, pitch, 64, 64)
+        ref = oracle.render(64, 64, 4, spheres=pt.scene_cornell(), basis=basis, eye=(x, y, z), max_bounces=8, rng_state=st)
+    names, planes = _read_feature_exr(out + ".exr")
+    k = names.index("Color.R")
+    assert np.array_equal(planes[k].view(np.uint32), ref[..., 0].view(np.uint32))
+    k = names.index("DepthVar.Z")
+    assert np.array_equal(planes[k].view(np.uint32), ref[..., 13].view(np.uint32))
