@@ -373,11 +373,15 @@ __device__ __forceinline__ bool intersect_sphere_nb(F3 o, F3 d, const RayConst& 
   bool bad_here = false;
   double sq = sqrt_cr_nb(disc, bad_here);
   double nb = (double)(-b);
-  float tn = quotient_to_float_nb(nb - sq, rc, bad_here);
-  float tf = quotient_to_float_nb(nb + sq, rc, bad_here);
+  // The reference returns tNear if it is positive, else tFar (tNear <= tFar always: same
+  // denominator 2a > 0, monotonic rounding).  tNear > 0 <=> nb - sq > 0 (the quotient keeps the
+  // sign; a positive quotient that would round to float zero is outside the checked range and
+  // goes to the literal code), so only that one quotient is evaluated.
+  const double n_near = nb - sq;
+  const double num = (n_near > 0.0) ? n_near : nb + sq;
+  t = quotient_to_float_nb(num, rc, bad_here);
   const bool real = det >= 0.0f;
   bad = bad | (real & bad_here);  // a negative or non-finite disc under det >= 0 lands here too
-  t = (tn > 0.0f && tf > 0.0f) ? fminf(tn, tf) : (tn > 0.0f ? tn : tf);
   return real;
 }
 

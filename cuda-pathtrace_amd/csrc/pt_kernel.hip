@@ -619,6 +619,11 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     float t[P];
     int idx[P];
     intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
+    // stage 1 (straight-line for all paths, so their chains interleave): materials, draws, fast geometry
+    F3 centre[P], emis[P], scol[P];
+    float u_az[P], u_el[P];
+    BounceGeom bg[P];
+    bool bad[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
       const bool was_alive = alive[p];
@@ -628,24 +633,35 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
       const float4 g = sc.geom[ix];
       const float4 m0 = sc.mat0[ix];
       const float4 m1 = sc.mat1[ix];
-      const F3 emis = mk3(m0.x, m0.y, m0.z);
-      const F3 scol = mk3(m0.w, m1.x, m1.y);
-      float u_az = 0.5f, u_el = 0.5f;
-      if (alive[p]) rng[p].bounce(n, u_az, u_el);  // a dead path draws nothing
-      bool bad = false;
-      BounceGeom bg = bounce_geometry<true>(o[p], d[p], t[p], mk3(g.x, g.y, g.z), u_az, u_el, bad);
-      if (__builtin_expect(bad & alive[p], 0)) bg = bounce_geometry<false>(o[p], d[p], t[p], mk3(g.x, g.y, g.z), u_az, u_el, bad);
-      const F3 me = mask[p] * emis;
+      centre[p] = mk3(g.x, g.y, g.z);
+      emis[p] = mk3(m0.x, m0.y, m0.z);
+      scol[p] = mk3(m0.w, m1.x, m1.y);
+      u_az[p] = 0.5f;
+      u_el[p] = 0.5f;
+      if (alive[p]) rng[p].bounce(n, u_az[p], u_el[p]);  // a dead path draws nothing
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      bad[p] = false;
+      bg[p] = bounce_geometry<true>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p]);
+    }
+    // stage 2: rare literal redo, then commit
+#pragma unroll
+    for (int p = 0; p < P; p++)
+      if (__builtin_expect(bad[p] & alive[p], 0)) bg[p] = bounce_geometry<false>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p]);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const F3 me = mask[p] * emis[p];
       const F3 add = (n == 0) ? mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f)) : me;  // :171-174
       if (alive[p]) {
         color[p] = color[p] + add;
-        mask[p] = mask[p] * scol;  // :175
-        o[p] = bg.o;
-        d[p] = bg.d;
+        mask[p] = mask[p] * scol[p];  // :175
+        o[p] = bg[p].o;
+        d[p] = bg[p].d;
         if (n == 0) {  // :187-195 (accumulated by the caller)
           res[p].hit0 = true;
-          res[p].normal0 = bg.normal;
-          res[p].albedo0 = scol;
+          res[p].normal0 = bg[p].normal;
+          res[p].albedo0 = scol[p];
           res[p].t0 = t[p];
         }
       }

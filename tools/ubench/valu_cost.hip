@@ -209,5 +209,28 @@ int main() {
     if (base == 0) base = ns;
     printf("%-16s %10.3f %14.3f %10.2f\n", e.name, best, ns, ns / base);
   }
+  // per-wave issue limit: same kernels with 1, 2, 4, 8 waves per SIMD (one block = 4 waves = 1 per SIMD)
+  printf("\nissue rate vs occupancy (ns per instruction per WAVE; ideal = constant x waves)\n");
+  Entry sweep[] = {E(add_f32), E(fma_f32), E(fma_f64), E(cmp_cnd_vcc_pair), E(rcp_f32)};
+  for (auto& e : sweep) {
+    printf("%-18s", e.name);
+    for (int wps = 1; wps <= 8; wps *= 2) {
+      const int nb = cus * wps;
+      hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, 1.0f);
+      CHECK(hipDeviceSynchronize());
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, 1.0f);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+      }
+      printf("  %d w/SIMD: %6.3f ns/instr/wave (%5.3f per SIMD)", wps, best * 1e6 / ((double)ITER * 8), best * 1e6 / ((double)ITER * 8 * wps));
+    }
+    printf("\n");
+  }
   return 0;
 }
