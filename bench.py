@@ -171,6 +171,20 @@ def main():
                 traffic = json.load(open(pmc)).get(f"{args.rng}_v{renderer.variant}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        vr = os.path.join(ROOT, "profiles", "valu_roofline.json")
+        if os.path.exists(vr) and world == 1 and spp == SPP:
+            try:
+                rec = json.load(open(vr)).get(f"{args.rng}_v{renderer.variant}")
+                if rec:  # instruction count per launch is a property of the code; the rate uses THIS run's kernel time
+                    ach = rec["valu_insts_per_launch"] / kernel_s / 1e9
+                    valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(rec["peak_ginst_per_s"], 1),
+                            "unit": "G wave-instr/s", "frac": round(ach / rec["peak_ginst_per_s"], 4),
+                            "fp32_tflops": round(rec["fp32_tflops"] * rec["kernel_ms"] / (kernel_s * 1e3), 2),
+                            "fp64_tflops": round(rec["fp64_tflops"] * rec["kernel_ms"] / (kernel_s * 1e3), 2),
+                            "source": "profiles/valu_roofline.json (rocprofv3 SQ_INSTS_VALU*; peak = measured v_add_f32 issue rate)"}
+            except Exception:
+                valu = None
         ki = renderer.kernel_info(len(spheres))
         out = {
             "metric": "Msamples/s, 9-sphere Cornell box 1024x1024x1024spp",
@@ -202,6 +216,7 @@ def main():
                 "note": "56 B/pixel/frame algorithmic; the kernel is VALU/latency bound (about 2.4 kFLOP per sample, "
                         "f32+f64), so the HBM fraction is <<1% by construction",
             },
+            "valu_roofline": valu,
             "kernel_info": ki,
         }
         if world == 1 and not args.no_cpu_baseline:

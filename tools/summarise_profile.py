@@ -33,7 +33,7 @@ def pmc(sub):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 counters = {}
-for sub in ("pmc_sq", "pmc_sq2", "pmc_write", "pmc_fetch"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_mix1", "pmc_mix2", "pmc_write", "pmc_fetch"):
     c, n = pmc(sub)
     counters.update(c)
 out["pmc_per_launch_avg"] = counters
@@ -47,6 +47,27 @@ if counters.get("SQ_BUSY_CYCLES") and counters.get("SQ_ACTIVE_INST_VALU"):
         "active_inst_valu_over_wave_cycles": counters["SQ_ACTIVE_INST_VALU"] / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
         "wait_inst_any_over_wave_cycles": counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
         "wait_any_over_wave_cycles": counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
+    }
+# VALU issue utilisation: instruction classes x the issue costs measured by tools/ubench/valu_cost
+# (units of one v_add_f32 = UNIT_NS per wave-instruction per SIMD at full occupancy)
+UNIT_NS = 1.125
+COST = {"SQ_INSTS_VALU_ADD_F32": 1.0, "SQ_INSTS_VALU_MUL_F32": 1.0, "SQ_INSTS_VALU_FMA_F32": 1.42, "SQ_INSTS_VALU_TRANS_F32": 3.0,
+        "SQ_INSTS_VALU_ADD_F64": 1.53, "SQ_INSTS_VALU_MUL_F64": 1.58, "SQ_INSTS_VALU_FMA_F64": 1.60, "SQ_INSTS_VALU_TRANS_F64": 6.0,
+        "SQ_INSTS_VALU_CVT": 1.52, "SQ_INSTS_VALU_INT32": 1.3, "SQ_INSTS_VALU_INT64": 1.55}
+if all(k in counters for k in COST) and "SQ_INSTS_VALU" in counters and st:
+    classified = sum(counters[k] for k in COST)
+    other = max(counters["SQ_INSTS_VALU"] - classified, 0.0)  # compares, selects, min/max, moves, bit ops
+    units = sum(counters[k] * c for k, c in COST.items()) + other * 1.35
+    kern = next(r for r in out["kernel_stats"] if "pixel_kernel" in r["Name"])
+    t_ns = float(kern["AverageNs"])
+    simds = 256 * 4
+    out["valu"] = {
+        "insts_per_launch": counters["SQ_INSTS_VALU"], "classified_fraction": classified / counters["SQ_INSTS_VALU"],
+        "issue_units_per_launch": units, "unit_ns": UNIT_NS, "simds": simds,
+        "issue_bound_ms": units * UNIT_NS / simds / 1e6, "kernel_ms": t_ns / 1e6,
+        "issue_utilisation": units * UNIT_NS / simds / t_ns,
+        "flops_fp32": counters.get("SQ_INSTS_VALU_FLOPS_FP32"), "flops_fp64": counters.get("SQ_INSTS_VALU_FLOPS_FP64"),
+        "mix": {k.replace("SQ_INSTS_VALU_", ""): counters[k] for k in COST},
     }
 for log in ("stats.log",):
     p = os.path.join(src, log)
