@@ -365,33 +365,50 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
   float T1 = INF, T2 = INF;
   int i1 = 0;
   bool unsure = false;
-  for (int i = 0; i < n; i++) {
-    const float4 g = sc.geom[i];
+  struct Head {
+    float b, a4c, bb, dacc;
+    uint32_t dd;
+  };
+  auto head = [&](const float4 g) {  // the contract's float part: decides det >= 0 exactly
     const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-    const float b = 2.0f * dot(d, off);
+    Head h;
+    h.b = 2.0f * dot(d, off);
     const float c = dot(off, off) - g.w;
-    const float bb = b * b;
-    const float a4c = rc.a4 * c;
-    const float det = bb - a4c;
-    const float dacc = fmaf(-rc.a4, c, bb);
-    const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
-    if (__builtin_amdgcn_ballot_w64((int)dd >= 0) == 0) continue;  // nobody in the wave hits this sphere
-    const float s = __builtin_amdgcn_sqrtf(dacc);
-    const float q = b + copysignf(s, b);
-    const float e = fmaf(b, b, -bb);
-    const float num = a4c + e;
+    h.bb = h.b * h.b;
+    h.a4c = rc.a4 * c;
+    const float det = h.bb - h.a4c;
+    h.dacc = fmaf(-rc.a4, c, h.bb);
+    h.dd = __float_as_uint(det) | __float_as_uint(h.dacc);
+    return h;
+  };
+  auto tail = [&](const Head& h, int i) {  // estimate + ranking, only when some lane really hits
+    if (__builtin_amdgcn_ballot_w64((int)h.dd >= 0) == 0) return;
+    const float s = __builtin_amdgcn_sqrtf(h.dacc);
+    const float q = h.b + copysignf(s, h.b);
+    const float e = fmaf(h.b, h.b, -h.bb);
+    const float num = h.a4c + e;
     const float TA = -q;
     const float TB = -num * __builtin_amdgcn_rcpf(q);
     const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
     const float T = lo > 0.0f ? lo : hi;
-    const bool ok = ((int)(dd | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
-    unsure = unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+    const bool ok = ((int)(h.dd | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
+    unsure = unsure | (((int)h.dd >= 0) & !(fabsf(num) > fabsf(h.a4c) * 4.7683716e-07f));
     const float Te = ok ? T : INF;
     const bool c1 = Te < T1, c2 = Te < T2;
     T2 = c1 ? T1 : (c2 ? Te : T2);
     i1 = c1 ? i : i1;
     T1 = c1 ? Te : T1;
+  };
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {  // four LDS reads and four float parts in flight, then the conditional tails
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2], g3 = sc.geom[i + 3];
+    const Head h0 = head(g0), h1 = head(g1), h2 = head(g2), h3 = head(g3);
+    tail(h0, i);
+    tail(h1, i + 1);
+    tail(h2, i + 2);
+    tail(h3, i + 3);
   }
+  for (; i < n; i++) tail(head(sc.geom[i]), i);
   const bool has = T1 < INF;
   bool ambiguous = unsure | (has & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
   float t;
