@@ -300,3 +300,51 @@ def test_cli_fly_through_matches_frame_by_frame_oracle(pt, oracle, gpu, tmp_path
     assert np.array_equal(planes[k].view(np.uint32), ref[..., 0].view(np.uint32))
     k = names.index("DepthVar.Z")
     assert np.array_equal(planes[k].view(np.uint32), ref[..., 13].view(np.uint32))
+
+
+# ---- fuzz: random scenes and cameras, every variant ----------------------------------------------------
+def _random_scene(rng, n):
+    s = np.zeros(n, dtype=np.dtype([("radius", "<f4"), ("pos", "<f4", 3), ("emission", "<f4", 3), ("color", "<f4", 3)]))
+    kind = rng.integers(0, 4, n)
+    for i in range(n):
+        if kind[i] == 0:      # small sphere somewhere in front of the camera
+            s["radius"][i] = rng.uniform(0.5, 20.0)
+            s["pos"][i] = rng.uniform([0, 0, 0], [100, 80, 170])
+        elif kind[i] == 1:    # huge "wall" sphere the camera is inside of
+            r = 10.0 ** rng.uniform(3, 5)
+            axis = rng.integers(0, 3)
+            sign = rng.choice([-1.0, 1.0])
+            p = np.array([50.0, 40.0, 80.0])
+            p[axis] += sign * (r - rng.uniform(20, 120))
+            s["radius"][i], s["pos"][i] = r, p
+        elif kind[i] == 2:    # sphere containing the camera position region partially (origin near surface)
+            s["radius"][i] = rng.uniform(30, 300)
+            s["pos"][i] = rng.uniform([-100, -100, 0], [200, 200, 400])
+        else:                 # concentric / coincident centres: exact ties between spheres
+            j = rng.integers(0, max(i, 1))
+            s["pos"][i] = s["pos"][j]
+            s["radius"][i] = s["radius"][j] if rng.random() < 0.5 else s["radius"][j] * rng.uniform(0.5, 1.5)
+        s["color"][i] = rng.uniform(0, 1, 3)
+        s["emission"][i] = rng.uniform(0, 5, 3) if rng.random() < 0.2 else 0.0
+    return s
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_random_scenes_all_variants(pt, oracle, gpu, seed):
+    """Random sphere soups (huge walls, nested and DUPLICATED spheres = exact ties, origins near
+    surfaces), random cameras, both generators: every variant must equal the oracle bit for bit.
+    Duplicated spheres force the first-index tie-break and the 'ambiguous -> literal loop' path."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 40)) if seed % 4 else int(rng.integers(65, 120))  # also the > 64-sphere path
+    scene = _random_scene(rng, n)
+    size = 48
+    eye = tuple(rng.uniform([20, 20, 100], [80, 60, 300]))
+    basis = pt.camera_basis(eye, float(rng.uniform(-120, -60)), float(rng.uniform(-20, 20)), size, size)
+    mode = int(seed % 2)
+    spp = int(rng.integers(1, 7))
+    mb = int(rng.integers(1, 9))
+    ref = oracle.render(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb)
+    assert np.isfinite(ref).all()
+    for v in range(_num_variants(pt)):
+        img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
+        assert_bit_exact(img, ref, f"fuzz seed {seed} n={n} spp={spp} bounces={mb} variant {v}")
