@@ -119,22 +119,34 @@ def main():
     basis = pt.camera_basis(width=WIDTH, height=HEIGHT)
     eye = pt.DEFAULT_EYE
 
-    fg = tiling.FrameGather(WIDTH, HEIGHT, device)
+    # two frame/tile buffer sets: the gather of step k (RCCL stream) overlaps the render of step k+1
+    fgs = [tiling.FrameGather(WIDTH, HEIGHT, device) for _ in range(2 if world > 1 else 1)]
+    fg = fgs[0]
+    pending = [[] for _ in fgs]
     rb, re_ = fg.rows
     renderer = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant,
                            persist_rng=True)
     d_scene = torch.from_numpy(spheres.view("u1").reshape(-1).copy()).to(device)
     stream = torch.cuda.current_stream()
 
+    step_no = [0]
+
     def step(ev=None):
+        slot = step_no[0] % len(fgs)
+        step_no[0] += 1
+        f = fgs[slot]
+        f.wait_all(pending[slot])  # the gather that last used this buffer set must have finished
         if ev is not None:
             ev[0].record(stream)
-        renderer.enqueue(fg.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
+        renderer.enqueue(f.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
         if ev is not None:
             ev[1].record(stream)
-        fg.wait_all(fg.gather())
+        pending[slot] = f.gather()
 
     def sync():
+        for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
+            f.wait_all(pending[slot])
+            pending[slot] = []
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -158,7 +170,8 @@ def main():
     if rank == 0 and args.dump:
         import numpy as np
 
-        np.save(args.dump, fg.frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+        last = fgs[(step_no[0] - 1) % len(fgs)]
+        np.save(args.dump, last.frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
     if rank == 0:
         total_samples = WIDTH * HEIGHT * spp * args.steps
         ms_per_step = elapsed / args.steps * 1e3
