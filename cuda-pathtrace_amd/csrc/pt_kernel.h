@@ -21,8 +21,9 @@
 #define PT_MIN_WAVES 1  // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
 #endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
-// use all of it, but we leave room for two resident workgroups).
-#define PT_LDS_BUDGET_BYTES (64 * 1024)
+// use all of it; this budget still lets a full-size scene run with one workgroup per CU and the
+// 9-sphere scene with many).
+#define PT_LDS_BUDGET_BYTES (96 * 1024)
 
 // Everything pixel_kernel needs travels as kernel arguments (SGPRs): the camera is 60 B, so
 // the reference's two per-frame cudaMemcpy H2D (Renderer.h:59-60) disappear.
@@ -39,6 +40,7 @@ struct PixelKernelArgs {
   int32_t spp;
   int32_t max_bounces;
   uint32_t frame;
+  uint32_t scene_lds_f4;       // float4 slots of the LDS scene image (filled in by the launcher)
   uint64_t seed;
 };
 

@@ -709,14 +709,14 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;  // pixel index inside the tile
-  if (tp >= a.tile_pixels) return;
+  const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
   const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
   const int col = (int)(tp % (uint32_t)a.width);
   const uint32_t id = (uint32_t)row * (uint32_t)a.width + (uint32_t)col;  // :206
 
   Rng<RNG> rng;
   if constexpr (RNG == PT_RNG_XORWOW) {
-    if (a.rng_state) {  // :212
+    if (a.rng_state && active) {  // :212
       const uint32_t* s = a.rng_state + (size_t)tp * 6;
       rng.st = Xorwow{s[0], s[1], s[2], s[3], s[4], s[5]};
     } else {
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
     dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
   };
 
-  int i = 0;
+  int i = active ? 0 : a.spp;  // inactive lanes trace nothing
   if constexpr (VAR >= 7) {
     const int draws = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;  // consumed by a path that never escapes
     for (; i + 2 <= a.spp; i += 2) {
@@ -785,24 +785,35 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   }
 
   const float fs = (float)a.spp;  // :234-237
-  float* o = a.out + (size_t)tp * 14;
-  o[0] = L.color.x / fs;
-  o[1] = L.color.y / fs;
-  o[2] = L.color.z / fs;
-  o[3] = L.normal.x / fs;
-  o[4] = L.normal.y / fs;
-  o[5] = L.normal.z / fs;
-  o[6] = L.albedo.x / fs;
-  o[7] = L.albedo.y / fs;
-  o[8] = L.albedo.z / fs;
-  o[9] = L.depth / fs;
-  o[10] = welford_variance(var[0]);  // :251-254
-  o[11] = welford_variance(var[1]);
-  o[12] = welford_variance(var[2]);
-  o[13] = welford_variance(var[3]);
+  const float px[14] = {L.color.x / fs,  L.color.y / fs,  L.color.z / fs,  L.normal.x / fs, L.normal.y / fs,
+                        L.normal.z / fs, L.albedo.x / fs, L.albedo.y / fs, L.albedo.z / fs, L.depth / fs,
+                        welford_variance(var[0]), welford_variance(var[1]), welford_variance(var[2]),
+                        welford_variance(var[3])};  // :240-254
+  // The 64 pixels of a wave are 64 consecutive columns, so their 64 x 14 floats are ONE contiguous
+  // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
+  // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u);
+  if (wave_full) {
+    float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
+#pragma unroll
+    for (int c = 0; c < 14; c++) wl[lane * 14 + c] = px[c];
+    __builtin_amdgcn_wave_barrier();  // DS operations of one wave execute in order: the reads below see these writes
+    const float4* src = reinterpret_cast<const float4*>(wl);
+    float4* dst = reinterpret_cast<float4*>(a.out + (size_t)(tp - (uint32_t)lane) * 14);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int q = lane + 64 * k;
+      if (q < 224) dst[q] = src[q];
+    }
+  } else if (active) {
+    float* o = a.out + (size_t)tp * 14;
+#pragma unroll
+    for (int c = 0; c < 14; c++) o[c] = px[c];
+  }
 
   if constexpr (RNG == PT_RNG_XORWOW) {
-    if (a.rng_state) {  // :256
+    if (a.rng_state && active) {  // :256
       uint32_t* s = a.rng_state + (size_t)tp * 6;
       s[0] = rng.st.d;
       s[1] = rng.st.v0;
@@ -834,7 +845,9 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 }  // namespace pt
 
 // ---- launchers (host) ---------------------------------------------------------------------
-static inline size_t scene_lds_bytes(int n) { return ((size_t)n * 3 + (size_t)((n + 1) / 2) * 2) * sizeof(float4); }
+static inline size_t scene_lds_f4(int n) { return (size_t)n * 3 + (size_t)((n + 1) / 2) * 2; }
+// scene image + one 64 x 14 float transpose slice per wave for the epilogue
+static inline size_t scene_lds_bytes(int n) { return scene_lds_f4(n) * sizeof(float4) + (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float); }
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
@@ -864,14 +877,20 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
 
 int pt_kernel_max_spheres(int variant) {
   (void)variant;
-  return (int)(PT_LDS_BUDGET_BYTES / (4 * sizeof(float4))) - 1;
+  return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float)) / (4 * sizeof(float4))) - 1;
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
   pixel_kernel_fn fn = select_kernel(rng_mode, variant);
   if (!fn) return hipErrorInvalidValue;
   const unsigned grid = (a.tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), scene_lds_bytes(a.n_spheres), stream, a);
+  PixelKernelArgs b = a;
+  b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres);
+  if (scene_lds_bytes(a.n_spheres) > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), scene_lds_bytes(a.n_spheres), stream, b);
   return hipGetLastError();
 }
 
