@@ -112,8 +112,10 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
 static int setup_random(pt_renderer* r) {
   if (!r->d_state) return PT_OK;
   PT_HIP(pt_launch_setup_random(r->d_state, r->width, r->opts.row_begin, r->tile_pixels, r->opts.seed, nullptr));
-  // the reference launches setup_random unchecked and unsynchronised (Renderer.h:38); the
-  // next launch on the same stream orders after it, so no sync is needed here either.
+  // The reference launches setup_random unchecked and unsynchronised (Renderer.h:38) because its
+  // only stream orders the next launch after it.  pt_renderer_enqueue may run on ANY caller stream
+  // (possibly non-blocking with respect to the default stream), so finish the 10 us kernel here.
+  PT_HIP(hipStreamSynchronize(nullptr));
   return PT_OK;
 }
 
