@@ -181,14 +181,14 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc) and world == 1 and spp == SPP:
             try:
-                traffic = json.load(open(pmc)).get(f"{args.rng}_v{renderer.variant}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"{args.rng}_v{renderer.kernel_info(len(spheres))['variant']}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         valu = None
         vr = os.path.join(ROOT, "profiles", "valu_roofline.json")
         if os.path.exists(vr) and world == 1 and spp == SPP:
             try:
-                rec = json.load(open(vr)).get(f"{args.rng}_v{renderer.variant}")
+                rec = json.load(open(vr)).get(f"{args.rng}_v{renderer.kernel_info(len(spheres))['variant']}")
                 if rec:  # instruction count per launch is a property of the code; the rate uses THIS run's kernel time
                     ach = rec["valu_insts_per_launch"] / kernel_s / 1e9
                     valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(rec["peak_ginst_per_s"], 1),
@@ -215,7 +215,7 @@ def main():
             "config": {
                 "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id (BASELINE.json configs[1])",
                 "tiling": f"rows/{world} + gather to rank 0 ({backend})" if world > 1 else "single GPU",
-                "kernel_variant": renderer.variant,
+                "kernel_variant": ki["variant"],
             },
             "roofline": {
                 "bound": "hbm",

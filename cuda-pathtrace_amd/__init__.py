@@ -62,6 +62,7 @@ class KernelInfo(ctypes.Structure):
         ("num_sgprs", ctypes.c_int32),
         ("scratch_bytes", ctypes.c_int32),
         ("max_spheres", ctypes.c_int32),
+        ("variant", ctypes.c_int32),
     ]
 
 

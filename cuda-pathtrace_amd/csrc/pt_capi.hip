@@ -39,7 +39,31 @@ struct pt_renderer {
   uint32_t* d_state;  // xorwow persistent state (Renderer::d_states), or nullptr
   hipEvent_t ev_start, ev_stop;
   int device;
+  int launch_variant;      // what fill_args chose for the launch being prepared
+  // automatic variant choice (opts.variant == PT_VARIANT_AUTO)
+  bool auto_variant;
+  bool small_tile;         // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD one-lane-per-pixel waves per SIMD
+  bool spec_ok;            // variant 8's speculation has not been failing on this scene
+  uint32_t* d_fail;        // device counter written by variant 8
+  uint32_t* h_fail;        // pinned host copy, valid once ev_fail has completed
+  hipEvent_t ev_fail;
+  bool fail_pending;
 };
+
+// Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD (measured:
+// 4 waves/SIMD: 21.3 vs 22.3 ms, 2 waves/SIMD: 11.3 vs 12.7 ms, 8 and more: variant 6 wins).
+#define PT_SPLIT_MAX_WAVES_PER_SIMD 6
+
+static int effective_variant(pt_renderer* r) {
+  if (!r->auto_variant) return r->opts.variant;
+  if (r->fail_pending && hipEventQuery(r->ev_fail) == hipSuccess) {
+    r->fail_pending = false;
+    if (*r->h_fail > r->tile_pixels / 50u) r->spec_ok = false;  // > 2 % of the pixels left speculative mode: an open scene
+  }
+  // splitting needs enough samples to amortise the generator skip-ahead (none for the counter-based philox)
+  const int min_spp = r->opts.rng_mode == PT_RNG_PHILOX ? 4 : 8;
+  return (r->small_tile && r->spec_ok && r->spp >= min_spp) ? 8 : PT_DEFAULT_VARIANT;
+}
 
 extern "C" {
 
@@ -106,7 +130,7 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
   o->max_bounces = 5;
   o->rng_mode = PT_RNG_XORWOW;
   o->persist_rng = 1;
-  o->variant = PT_DEFAULT_VARIANT;
+  o->variant = PT_VARIANT_AUTO;
 }
 
 static int setup_random(pt_renderer* r) {
@@ -134,7 +158,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.max_bounces < 0 || o.max_bounces > 64) return pt_fail(PT_EINVAL, "pt_renderer_create: max_bounces %d", o.max_bounces);
   if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
     return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
-  if (o.variant < 0 || o.variant >= pt_kernel_num_variants())
+  if (o.variant != PT_VARIANT_AUTO && (o.variant < 0 || o.variant >= pt_kernel_num_variants()))
     return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d (have %d)", o.variant, pt_kernel_num_variants());
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
@@ -154,7 +178,26 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->frame = 0;
   r->d_state = nullptr;
   r->ev_start = r->ev_stop = nullptr;
+  r->auto_variant = (o.variant == PT_VARIANT_AUTO);
+  r->small_tile = false;
+  r->spec_ok = true;
+  r->d_fail = nullptr;
+  r->h_fail = nullptr;
+  r->ev_fail = nullptr;
+  r->fail_pending = false;
   hipError_t e = hipGetDevice(&r->device);
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, r->device);
+    if (e == hipSuccess) {
+      const uint64_t simds = (uint64_t)prop.multiProcessorCount * 4u;
+      r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD;
+    }
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&r->d_fail, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(r->d_fail, 0, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_fail, sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess) { *r->h_fail = 0; e = hipEventCreateWithFlags(&r->ev_fail, hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
   if (e == hipSuccess && o.rng_mode == PT_RNG_XORWOW && o.persist_rng && r->tile_pixels)
@@ -176,6 +219,9 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
 int pt_renderer_destroy(pt_renderer* r) {
   if (!r) return PT_OK;
   if (r->d_state) (void)hipFree(r->d_state);  // Renderer.h:50
+  if (r->d_fail) (void)hipFree(r->d_fail);
+  if (r->h_fail) (void)hipHostFree(r->h_fail);
+  if (r->ev_fail) (void)hipEventDestroy(r->ev_fail);
   if (r->ev_start) (void)hipEventDestroy(r->ev_start);
   if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
   delete r;
@@ -188,9 +234,13 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   if (!d_out && r->tile_pixels) return pt_fail(PT_EINVAL, "render: d_out is NULL");
   if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "render: bad scene (%d spheres)", n_spheres);
   if (!basis || !eye) return pt_fail(PT_EINVAL, "render: basis/eye is NULL");
-  if (n_spheres > pt_kernel_max_spheres(r->opts.variant))
+  const int variant = effective_variant(r);
+  if (n_spheres > pt_kernel_max_spheres(variant))
     return pt_fail(PT_ELIMIT, "render: %d spheres exceed the LDS staging limit of %d", n_spheres,
-                   pt_kernel_max_spheres(r->opts.variant));
+                   pt_kernel_max_spheres(variant));
+  a->fail_count = r->d_fail;
+  a->scene_lds_f4 = 0;
+  r->launch_variant = variant;
   a->out = d_out;
   a->spheres = d_spheres;
   a->rng_state = r->d_state;
@@ -208,13 +258,28 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   return PT_OK;
 }
 
+// One frame on `stream`; with the automatic policy a speculative launch also schedules the
+// asynchronous read-back of its failure counter (consulted by a later effective_variant()).
+static int launch(pt_renderer* r, const PixelKernelArgs& a, hipStream_t stream) {
+  const bool watch = r->auto_variant && r->launch_variant == 8 && !r->fail_pending;
+  if (watch) PT_HIP(hipMemsetAsync(r->d_fail, 0, sizeof(uint32_t), stream));
+  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->launch_variant, stream));
+  if (watch) {
+    PT_HIP(hipMemcpyAsync(r->h_fail, r->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    PT_HIP(hipEventRecord(r->ev_fail, stream));
+    r->fail_pending = true;
+  }
+  return PT_OK;
+}
+
 int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
                         const float eye[3], void* hip_stream) {
   PixelKernelArgs a;
   int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
   if (rc != PT_OK) return rc;
   if (r->tile_pixels == 0) return PT_OK;
-  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->opts.variant, (hipStream_t)hip_stream));
+  rc = launch(r, a, (hipStream_t)hip_stream);
+  if (rc != PT_OK) return rc;
   r->frame++;
   return PT_OK;
 }
@@ -227,7 +292,8 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   if (ms_out) *ms_out = 0.0f;
   if (r->tile_pixels == 0) return PT_OK;
   PT_HIP(hipEventRecord(r->ev_start, nullptr));  // Renderer.h:68
-  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->opts.variant, nullptr));
+  rc = launch(r, a, nullptr);
+  if (rc != PT_OK) return rc;
   PT_HIP(hipEventRecord(r->ev_stop, nullptr));   // Renderer.h:70
   PT_HIP(hipEventSynchronize(r->ev_stop));       // Renderer.h:72
   r->frame++;
@@ -268,14 +334,17 @@ int pt_renderer_set_rng_state(pt_renderer* r, const uint32_t* h_state, size_t n_
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info) {
   if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
   hipFuncAttributes fa;
-  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, r->opts.variant)));
+  const int variant = effective_variant(r);
+  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant)));
   info->block_threads = PT_BLOCK_THREADS;
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-  info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, r->opts.variant);
+  info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);
+  info->variant = variant;
+  if (variant == 8) info->grid_blocks = (int)(((uint64_t)r->tile_pixels * 4 + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;
-  info->max_spheres = pt_kernel_max_spheres(r->opts.variant);
+  info->max_spheres = pt_kernel_max_spheres(variant);
   return PT_OK;
 }
 

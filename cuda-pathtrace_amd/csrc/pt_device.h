@@ -65,6 +65,30 @@ __device__ __forceinline__ uint32_t xorwow_next(Xorwow& s) {
   return s.v4 + s.d;
 }
 
+// Advance the generator by n draws without producing outputs (variant 8's skip-ahead).  The
+// xorshift part rotates five words, so five steps written out need no register moves; the Weyl
+// counter d advances in one multiply.
+__device__ __forceinline__ void xorwow_skip(Xorwow& s, int n) {
+  s.d += 362437u * (uint32_t)n;
+  uint32_t v0 = s.v0, v1 = s.v1, v2 = s.v2, v3 = s.v3, v4 = s.v4;
+#define PT_XW_STEP(a, e) { const uint32_t t = (a) ^ ((a) >> 2); (a) = ((e) ^ ((e) << 4)) ^ (t ^ (t << 1)); }
+  // after a step the new v4 lives in the register that held v0: (v0,v1,v2,v3,v4) -> (v1,v2,v3,v4,new)
+  for (; n >= 5; n -= 5) {
+    PT_XW_STEP(v0, v4)  // new word in v0, logical order now v1 v2 v3 v4 v0
+    PT_XW_STEP(v1, v0)
+    PT_XW_STEP(v2, v1)
+    PT_XW_STEP(v3, v2)
+    PT_XW_STEP(v4, v3)  // logical order back to v0 v1 v2 v3 v4
+  }
+  for (; n > 0; n--) {
+    PT_XW_STEP(v0, v4)
+    const uint32_t nw = v0;
+    v0 = v1; v1 = v2; v2 = v3; v3 = v4; v4 = nw;
+  }
+#undef PT_XW_STEP
+  s.v0 = v0; s.v1 = v1; s.v2 = v2; s.v3 = v3; s.v4 = v4;
+}
+
 // curand_uniform: (0,1]
 __device__ __forceinline__ float uniform_from_u32(uint32_t x) {
   return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);

@@ -10,6 +10,7 @@
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // unroll factor of the screening loop (ILP at low occupancy)
 #endif
+#define PT_VARIANT_AUTO (-1)   // pt_renderer_opts_default(): variant 6, or 8 for small tiles (see pt_capi.hip)
 #define PT_DEFAULT_VARIANT 6  // what pt_renderer_opts_default() selects; 0 is the literal transcription
 #ifndef PT_SCREEN_MAX_SPHERES
 #define PT_SCREEN_MAX_SPHERES 64  // variant 5 screens scenes up to this size, larger ones use the literal loop
@@ -41,6 +42,7 @@ struct PixelKernelArgs {
   int32_t max_bounces;
   uint32_t frame;
   uint32_t scene_lds_f4;       // float4 slots of the LDS scene image (filled in by the launcher)
+  uint32_t* fail_count;        // variant 8: number of pixels whose speculation failed (may be nullptr)
   uint64_t seed;
 };
 

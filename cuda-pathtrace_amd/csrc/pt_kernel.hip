@@ -754,9 +754,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
     for (; i + 2 <= a.spp; i += 2) {
       Rng<RNG> g[2] = {rng, rng};
       g[0].begin_sample((uint32_t)i);
-      if constexpr (RNG == PT_RNG_XORWOW) {
-        for (int k = 0; k < draws; k++) (void)xorwow_next(g[1].st);
-      }
+      if constexpr (RNG == PT_RNG_XORWOW) xorwow_skip(g[1].st, draws);
       g[1].begin_sample((uint32_t)i + 1u);
       F3 o2[2] = {eye, eye}, d2[2];
       primary_ray(g[0], d2[0]);
@@ -825,6 +823,172 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   }
 }
 
+// ---- variant 8: four lanes per pixel (small tiles) ----------------------------------------------
+// A rank of an 8-GPU run renders 131 072 pixels = 2 waves per SIMD with one lane per pixel, which is
+// latency-bound.  Here lane (pixel, s) traces samples s, s+4, s+8, ... so the same tile
+// has 4x the waves.  What the contract fixes -- one sequential generator per pixel, sequential float
+// sums, sequential Welford updates -- is preserved:
+//  * xorwow: lane s starts from the pixel's state advanced by s*D draws and skips 3*D draws after each
+//    of its samples, D = 2 + 2*max_bounces being what a non-escaping path consumes (speculation);
+//  * after every round the four results are exchanged through the wave's LDS slice and applied IN
+//    SAMPLE ORDER, feature-parallel: lane 0 owns the colour sums + colour variance, lane 1 normal,
+//    lane 2 albedo, lane 3 depth -- the same additions and Welford updates as the one-lane kernel,
+//    just done by four lanes side by side;
+//  * if a sample that is not the frame's last one escapes (consumed fewer draws), every later
+//    speculative state of that pixel is wrong: the records after it are discarded and the group
+//    continues in sequential mode (lane 0 traces, all four still accumulate) from that sample's true
+//    final state.  Never happens in a closed scene; in an open one the kernel degrades to 1/4
+//    efficiency for that pixel but stays exact.
+constexpr int kSplit = 4;
+constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
+
+template <int RNG>
+__global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
+  extern __shared__ float4 lds_scene[];
+  const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
+  const int gbase = lane & ~(kSplit - 1);
+
+  const uint32_t gl = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
+  const uint32_t tp = gl / kSplit;      // pixel index inside the tile
+  const int s = (int)(gl % kSplit);     // sample slot AND the feature this lane accumulates
+  const bool active = tp < a.tile_pixels;
+  const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
+  const int col = (int)(tp % (uint32_t)a.width);
+  const uint32_t id = (uint32_t)row * (uint32_t)a.width + (uint32_t)col;
+
+  Rng<RNG> rng;
+  const int D = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;
+  if constexpr (RNG == PT_RNG_XORWOW) {
+    if (a.rng_state && active) {
+      const uint32_t* p = a.rng_state + (size_t)tp * 6;
+      rng.st = Xorwow{p[0], p[1], p[2], p[3], p[4], p[5]};
+    } else {
+      xorwow_init(rng.st, (uint64_t)id + a.seed);
+    }
+    xorwow_skip(rng.st, s * D);
+  } else {
+    rng.k0 = (uint32_t)a.seed;
+    rng.k1 = (uint32_t)(a.seed >> 32) ^ a.frame;
+    rng.pix = id;
+  }
+  Xorwow final_state = Xorwow{0, 0, 0, 0, 0, 0};
+  if constexpr (RNG == PT_RNG_XORWOW) final_state = rng.st;  // spp == 0 never happens; overwritten below
+
+  const F3 B0 = mk3(a.basis[0], a.basis[1], a.basis[2]), B1 = mk3(a.basis[3], a.basis[4], a.basis[5]);
+  const F3 B2 = mk3(a.basis[6], a.basis[7], a.basis[8]), B3 = mk3(a.basis[9], a.basis[10], a.basis[11]);
+  const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
+
+  float sum0 = 0.0f, sum1 = 0.0f, sum2 = 0.0f;  // this lane's feature sums (depth uses sum0 only)
+  Welford w{0, 0.0f, 0.0f};
+  bool seq = false;  // group-uniform: sequential mode after a failed speculation
+  int base = 0;      // group-uniform: first sample of the current round
+
+  while (base < a.spp) {
+    const int k = seq ? base : base + s;
+    const bool mine = active && (!seq || s == 0) && k < a.spp;
+    PathResult res[1];
+    res[0].color = res[0].normal0 = res[0].albedo0 = mk3(0.0f, 0.0f, 0.0f);
+    res[0].t0 = 0.0f;
+    res[0].hit0 = res[0].escaped = false;
+    if (mine) {
+      Rng<RNG> g[1] = {rng};
+      g[0].begin_sample((uint32_t)k);
+      float sx = (float)row, sy = (float)col;  // :221-229
+      if (a.spp != 1) {
+        float jx, jy;
+        g[0].jitter(jx, jy);
+        sx += jx * 1.0f - 0.5f;
+        sy += jy * 1.0f - 0.5f;
+      }
+      sx /= (float)a.height;
+      sy /= (float)a.width;
+      F3 o1[1] = {eye}, d1[1] = {lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx)};
+      trace_paths<RNG, 1>(res, sc, a.n_spheres, o1, d1, g, a.max_bounces);
+      rng = g[0];
+    }
+    // publish this lane's sample
+    float* rec = xl + lane * kRecWords;
+    const float lumC = luminance(res[0].color), lumN = luminance(res[0].normal0), lumA = luminance(res[0].albedo0);
+    *reinterpret_cast<float4*>(rec + 0) = make_float4(res[0].color.x, res[0].color.y, res[0].color.z, lumC);
+    *reinterpret_cast<float4*>(rec + 4) = make_float4(res[0].normal0.x, res[0].normal0.y, res[0].normal0.z, lumN);
+    *reinterpret_cast<float4*>(rec + 8) = make_float4(res[0].albedo0.x, res[0].albedo0.y, res[0].albedo0.z, lumA);
+    *reinterpret_cast<float4*>(rec + 12) = make_float4(res[0].t0, 0.0f, 0.0f, res[0].t0);
+    reinterpret_cast<uint32_t*>(rec)[16] = (mine ? 1u : 0u) | (res[0].hit0 ? 2u : 0u) | (res[0].escaped ? 4u : 0u);
+    if constexpr (RNG == PT_RNG_XORWOW) {
+      uint32_t* ru = reinterpret_cast<uint32_t*>(rec) + 17;
+      ru[0] = rng.st.d; ru[1] = rng.st.v0; ru[2] = rng.st.v1; ru[3] = rng.st.v2; ru[4] = rng.st.v3; ru[5] = rng.st.v4;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // apply the round's samples in order to this lane's feature
+    bool failed = false;
+    int consumed = 0;  // samples of this round that count (all of them unless a speculation failed)
+#pragma unroll
+    for (int j = 0; j < kSplit; j++) {
+      const float* rj = xl + (gbase + j) * kRecWords;
+      const uint32_t fl = reinterpret_cast<const uint32_t*>(rj)[16];
+      const bool valid = ((fl & 1u) != 0u) & !failed;
+      const bool hit0 = (fl & 2u) != 0u, esc = (fl & 4u) != 0u;
+      const float4 v = *reinterpret_cast<const float4*>(rj + 4 * s);
+      const bool en_sum = valid & ((s == 0) | hit0);                 // colour is always added (:159,:198); AOVs on a first hit (:187-190)
+      const bool en_w = valid & ((s == 0) ? !esc : hit0);             // :200 / :192-194
+      sum0 = en_sum ? sum0 + v.x : sum0;
+      sum1 = en_sum ? sum1 + v.y : sum1;
+      sum2 = en_sum ? sum2 + v.z : sum2;
+      Welford wn = w;
+      welford_update(wn, v.w);
+      w.n = en_w ? wn.n : w.n;  // field-wise: a struct select would go through scratch
+      w.mean = en_w ? wn.mean : w.mean;
+      w.M2 = en_w ? wn.M2 : w.M2;
+      if constexpr (RNG == PT_RNG_XORWOW) {
+        if (valid) {
+          const uint32_t* ru = reinterpret_cast<const uint32_t*>(rj) + 17;
+          final_state = Xorwow{ru[0], ru[1], ru[2], ru[3], ru[4], ru[5]};
+        }
+        const int kj = seq ? base : base + j;
+        if (valid & esc & !seq & (kj < a.spp - 1)) failed = true;  // later speculative states are wrong
+      }
+      consumed += valid ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();  // records are rewritten next round
+    if (!seq) {
+      if (failed) {
+        if (s == 0 && a.fail_count) atomicAdd(a.fail_count, 1u);  // lets the host stop speculating on open scenes
+        seq = true;
+        base += consumed;          // resume right after the escaped sample
+        if constexpr (RNG == PT_RNG_XORWOW) rng.st = final_state;  // its true final state (only lane 0 traces from here on)
+      } else {
+        base += kSplit;
+        if constexpr (RNG == PT_RNG_XORWOW) xorwow_skip(rng.st, (kSplit - 1) * D);
+      }
+    } else {
+      base += 1;
+      if constexpr (RNG == PT_RNG_XORWOW) rng.st = final_state;
+    }
+  }
+
+  if (active) {  // :234-254, each lane stores its feature
+    const float fs = (float)a.spp;
+    float* o = a.out + (size_t)tp * 14;
+    if (s < 3) {
+      o[3 * s + 0] = sum0 / fs;
+      o[3 * s + 1] = sum1 / fs;
+      o[3 * s + 2] = sum2 / fs;
+    } else {
+      o[9] = sum0 / fs;
+    }
+    o[10 + s] = welford_variance(w);
+    if constexpr (RNG == PT_RNG_XORWOW) {
+      if (a.rng_state && s == 0) {  // :256
+        uint32_t* p = a.rng_state + (size_t)tp * 6;
+        p[0] = final_state.d; p[1] = final_state.v0; p[2] = final_state.v1;
+        p[3] = final_state.v2; p[4] = final_state.v3; p[5] = final_state.v4;
+      }
+    }
+  }
+}
+
 // setup_random: src/pathtrace.cu:259-266
 __global__ void __launch_bounds__(PT_BLOCK_THREADS)
     setup_random_kernel(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed) {
@@ -851,6 +1015,10 @@ static inline size_t scene_lds_bytes(int n) { return scene_lds_f4(n) * sizeof(fl
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
+static inline size_t split_lds_bytes(int n) {
+  return scene_lds_f4(n) * sizeof(float4) + (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
+}
+
 static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
   const bool philox = rng_mode == PT_RNG_PHILOX;
   switch (variant) {
@@ -862,25 +1030,40 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
     case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
     case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
+    case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX> : pt::pixel_kernel_split<PT_RNG_XORWOW>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 8; }
+int pt_kernel_num_variants(void) { return 9; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
-  (void)variant;
-  return scene_lds_bytes(n_spheres);
+  return variant == 8 ? split_lds_bytes(n_spheres) : scene_lds_bytes(n_spheres);
 }
 
 int pt_kernel_max_spheres(int variant) {
-  (void)variant;
+  if (variant == 8)
+    return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float)) / (4 * sizeof(float4))) - 1;
   return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float)) / (4 * sizeof(float4))) - 1;
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
+  if (variant == 8) {
+    PixelKernelArgs b = a;
+    b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres);
+    const size_t lds = split_lds_bytes(a.n_spheres);
+    pixel_kernel_fn fs = rng_mode == PT_RNG_PHILOX ? pt::pixel_kernel_split<PT_RNG_PHILOX> : pt::pixel_kernel_split<PT_RNG_XORWOW>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)fs, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
+      if (e != hipSuccess) return e;
+    }
+    const uint64_t lanes = (uint64_t)a.tile_pixels * pt::kSplit;
+    const unsigned grid = (unsigned)((lanes + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+    hipLaunchKernelGGL(fs, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, b);
+    return hipGetLastError();
+  }
   pixel_kernel_fn fn = select_kernel(rng_mode, variant);
   if (!fn) return hipErrorInvalidValue;
   const unsigned grid = (a.tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;

@@ -68,8 +68,9 @@ typedef struct pt_renderer_opts {
   int32_t row_end;      /*   rendered by this renderer (multi-GPU row tiling); 0,0 = all   */
   int32_t persist_rng;  /* xorwow only: keep per-pixel generator state across Render()     */
                         /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
-  int32_t variant;      /* kernel variant; pt_renderer_opts_default() selects the fastest one,     */
-                        /*   0 = literal transcription; all variants produce identical bits       */
+  int32_t variant;      /* kernel variant, all produce identical bits: -1 (default) = automatic    */
+                        /*   (6, or 8 = four lanes per pixel when the tile is too small to fill    */
+                        /*   the GPU), 0 = literal transcription, 1..8 see DESIGN.md               */
 } pt_renderer_opts;
 
 typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */
@@ -141,6 +142,7 @@ typedef struct pt_kernel_info {
   int32_t num_sgprs;
   int32_t scratch_bytes;
   int32_t max_spheres;  /* LDS staging limit for this variant */
+  int32_t variant;      /* the variant the next launch will use (resolves the automatic choice) */
 } pt_kernel_info;
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info);
 

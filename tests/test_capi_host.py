@@ -33,7 +33,7 @@ def test_abi_version_and_struct_layout(pt):
     assert ctypes.sizeof(pt.RendererOpts) == 32
     o = pt.RendererOpts()
     pt.lib.pt_renderer_opts_default(ctypes.byref(o))
-    assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng) == (5, 0, 0, 1) and o.variant >= 0
+    assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant) == (5, 0, 0, 1, -1)
 
 
 def test_cornell_scene_matches_oracle_table(pt, oracle):

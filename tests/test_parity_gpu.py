@@ -348,3 +348,29 @@ def test_fuzz_random_scenes_all_variants(pt, oracle, gpu, seed):
     for v in range(_num_variants(pt)):
         img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
         assert_bit_exact(img, ref, f"fuzz seed {seed} n={n} spp={spp} bounces={mb} variant {v}")
+
+
+def test_automatic_variant_policy(pt, oracle, gpu):
+    """Default options: small tiles use the four-lanes-per-pixel kernel (variant 8); a renderer whose
+    scene turns out to be open (speculation keeps failing) goes back to variant 6; large tiles use
+    variant 6 from the start.  Whatever is chosen, frames stay bit-identical to the oracle."""
+    size, spp = 256, 8
+    basis = pt.camera_basis(width=size, height=size)
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    for name, sph, expect_after in (("closed", pt.scene_cornell(), 8), ("open", pt.scene_cornell()[[6, 7, 8]], 6)):
+        r = pt.Renderer(size, size, spp)  # variant left to the library
+        d_scene, n = pt.upload_scene(sph)
+        assert r.kernel_info(n)["variant"] == 8, name
+        st = oracle.setup_random(size, size)
+        for frame in range(3):
+            r.render(d_out.ptr, d_scene.ptr, n, basis)
+            ref = oracle.render(size, size, spp, spheres=sph, basis=basis, rng_state=st)
+            assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, f"{name} frame {frame}")
+        assert r.kernel_info(n)["variant"] == expect_after, name
+        r.destroy()
+    big = pt.Renderer(1024, 1024, 8)
+    assert big.kernel_info(9)["variant"] == 6
+    big.destroy()
+    few = pt.Renderer(256, 256, 2)  # too few samples to split
+    assert few.kernel_info(9)["variant"] == 6
+    few.destroy()

@@ -13,7 +13,7 @@ import __graft_entry__ as ge
 
 pt = ge.load_package()
 pt.set_device(0)
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else None  # None = the library's automatic choice
 out = {"variant": variant, "device": pt.device_info()}
 
 
@@ -24,9 +24,10 @@ def run(name, size, spp, spheres, reps=3, rows=None, **kw):
     d_scene, n = pt.upload_scene(spheres)
     d_out = pt.DeviceBuffer((re_ - rb) * size * 14 * 4)
     ms = [r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(reps)]
+    used = r.kernel_info(n)["variant"]
     r.destroy()
     samples = (re_ - rb) * size * spp
-    res = {"ms_min": round(min(ms), 3), "ms_all": [round(m, 3) for m in ms], "Msamples_per_s": round(samples / min(ms) / 1e3, 1)}
+    res = {"variant": used, "ms_min": round(min(ms), 3), "ms_all": [round(m, 3) for m in ms], "Msamples_per_s": round(samples / min(ms) / 1e3, 1)}
     out[name] = res
     print(name, res, flush=True)
 
@@ -52,4 +53,4 @@ for _ in range(5):
     ts.append((time.perf_counter() - t) * 1e3)
 out["d2h_58.7MB_ms"] = [round(x, 3) for x in ts]
 print("d2h 58.7 MB ms", out["d2h_58.7MB_ms"], flush=True)
-json.dump(out, open(os.path.join("gpurun_out", f"config_times_v{variant}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join("gpurun_out", f"config_times_v{variant if variant is not None else 'auto'}.json"), "w"), indent=1)
