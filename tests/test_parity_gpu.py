@@ -374,3 +374,24 @@ def test_automatic_variant_policy(pt, oracle, gpu):
     few = pt.Renderer(256, 256, 2)  # too few samples to split
     assert few.kernel_info(9)["variant"] == 6
     few.destroy()
+
+
+@pytest.mark.parametrize("scene", ["closed", "open"])
+@pytest.mark.parametrize("spp", [3, 8, 13])
+def test_four_lane_kernel_keeps_generator_state_across_frames(pt, oracle, gpu, scene, spp):
+    """Variant 8 forced: the generator state written back after a frame must be the sequential one
+    (also when speculation failed and the pixel finished in sequential mode, and when spp is not a
+    multiple of four), so later frames continue the reference's stream."""
+    size = 40
+    sph = pt.scene_cornell() if scene == "closed" else pt.scene_cornell()[[1, 3, 6, 7, 8]]
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, spp, variant=8)
+    d_scene, n = pt.upload_scene(sph)
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    st = oracle.setup_random(size, size)
+    for frame in range(3):
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        ref = oracle.render(size, size, spp, spheres=sph, basis=basis, rng_state=st)
+        assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, f"{scene} spp {spp} frame {frame}")
+        assert np.array_equal(r.get_rng_state(), st), f"{scene} spp {spp}: generator state after frame {frame}"
+    r.destroy()
