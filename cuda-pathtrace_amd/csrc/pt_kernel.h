@@ -15,6 +15,9 @@
 #ifndef PT_SCREEN_MAX_SPHERES
 #define PT_SCREEN_MAX_SPHERES 64  // variant 5 screens scenes up to this size, larger ones use the literal loop
 #endif
+#ifndef PT_UNROLL_BOUNCES
+#define PT_UNROLL_BOUNCES 1  // also emit a fully unrolled path for the reference's MAX_BOUNCES = 5 (+6 %)
+#endif
 #ifndef PT_KERNEL_ATTR
 #define PT_KERNEL_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): let the scheduler spend registers on ILP
 #endif

@@ -448,12 +448,12 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
                                           Welford (&var)[4], int max_bounces) {
   F3 color = mk3(0.0f, 0.0f, 0.0f);
   F3 mask = mk3(1.0f, 1.0f, 1.0f);
-  for (int n = 0; n < max_bounces; n++) {
+  auto bounce = [&](int n) -> bool {  // one iteration of the loop at :155; false = the ray left the scene
     float t = 0.0f;
     int idx = 0;
     if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
       L.color = L.color + color;
-      return;
+      return false;
     }
     const float4 g = sc.geom[idx];
     const float4 m0 = sc.mat0[idx];
@@ -500,6 +500,18 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
       welford_update(var[2], luminance(scol));
       welford_update(var[3], t);
     }
+    return true;
+  };
+#if PT_UNROLL_BOUNCES
+  if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
+#pragma unroll
+    for (int n = 0; n < 5; n++)
+      if (!bounce(n)) return;
+  } else
+#endif
+  {
+    for (int n = 0; n < max_bounces; n++)
+      if (!bounce(n)) return;
   }
   L.color = L.color + color;                    // :198
   welford_update(var[0], luminance(color));     // :200
@@ -627,11 +639,11 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     res[p].albedo0 = mk3(0.0f, 0.0f, 0.0f);
     res[p].t0 = 0.0f;
   }
-  for (int n = 0; n < max_bounces; n++) {
+  auto bounce = [&](int n) -> bool {  // false = every path of this lane has left the scene
     bool any = false;
 #pragma unroll
     for (int p = 0; p < P; p++) any = any | alive[p];
-    if (!any) break;
+    if (!any) return false;
     bool hit[P];
     float t[P];
     int idx[P];
@@ -683,6 +695,18 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
         }
       }
     }
+    return true;
+  };
+#if PT_UNROLL_BOUNCES
+  if (P == 1 && max_bounces == 5) {
+#pragma unroll
+    for (int n = 0; n < 5; n++)
+      if (!bounce(n)) break;
+  } else
+#endif
+  {
+    for (int n = 0; n < max_bounces; n++)
+      if (!bounce(n)) break;
   }
 #pragma unroll
   for (int p = 0; p < P; p++) res[p].color = color[p];
