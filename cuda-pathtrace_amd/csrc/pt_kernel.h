@@ -18,6 +18,9 @@
 #ifndef PT_UNROLL_BOUNCES
 #define PT_UNROLL_BOUNCES 1  // also emit a fully unrolled path for the reference's MAX_BOUNCES = 5 (+6 %)
 #endif
+#ifndef PT_UNROLL_NINE
+#define PT_UNROLL_NINE 1  // also emit a fully unrolled screening pass for the reference's 9-sphere scene (+5 %)
+#endif
 #ifndef PT_KERNEL_ATTR
 #define PT_KERNEL_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): let the scheduler spend registers on ILP
 #endif

@@ -310,6 +310,13 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   // LDS reads are issued together and the three dependency chains interleave, which is what
   // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
   int i = 0;
+#if PT_UNROLL_NINE
+  if (n == 9) {  // the reference's scene size (Scene.h:23): constant LDS offsets and indices, no loop state
+#pragma unroll
+    for (int u = 0; u < 9; u++) screen(sc.geom[u], u);
+    i = 9;
+  }
+#endif
   for (; i + 3 <= n; i += 3) {
     const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2];
     screen(g0, i);
@@ -587,6 +594,13 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   const uint32_t imask = (1u << ib) - 1u;
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);
   int i = 0;
+#if PT_UNROLL_NINE
+  if (P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
+#pragma unroll
+    for (int u = 0; u < 9; u++) screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
+    i = 9;
+  }
+#endif
   for (; i + 2 <= n; i += 2) {
     const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1];
 #pragma unroll
