@@ -27,7 +27,7 @@ def main():
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and sym in l and l.split("#")[0].split(";")[0].rstrip().endswith(":"))
     blocks, cur = [], None
     for l in lines[start + 1:]:
-        if l.strip().startswith("s_endpgm"):
+        if l.startswith(".Lfunc_end"):
             break
         m = re.match(r"^(\.LBB\S+|; %bb\.\d+):?", l.strip())
         if m:
