@@ -1,0 +1,437 @@
+// pt_intersect.h -- nearest-hit search over the sphere list (src/pathtrace.cu:93-107) in all its
+// bit-identical forms: literal loop, screened (variants 2-6), many-sphere, and P rays at once.
+#pragma once
+#include "pt_scene_lds.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+// intersectScene: src/pathtrace.cu:93-107 -- literal loop (variants 0 and 1)
+template <int VAR>
+__device__ __forceinline__ bool intersect_scene_loop(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                     float& t_hit, int& idx) {
+  float tNearest = 1000000.0f;
+  float t = 0.0f;
+  bool hit = false;
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    bool h;
+    if constexpr (VAR == 0)
+      h = intersect_sphere(o, d, rc.a, g, t);
+    else
+      h = intersect_sphere_v1(o, d, rc, g, t);
+    if (h && t > 0.0f && t < tNearest) {
+      tNearest = t;
+      hit = true;
+      t_hit = t;
+      idx = i;
+    }
+  }
+  return hit;
+}
+
+// Variant 2: screen, then evaluate exactly once.
+//
+// Phase 1 runs the reference's float part of every sphere test (off, b, c, b*b, det: these ARE
+// the contract's values and decide `det >= 0` exactly) and adds a float32 estimate T ~ 2a*t of the
+// root the reference would return, from the cancellation-free forms q = b + sign(b)*s,
+// roots {-q, -(4ac + (b*b - bb))/q}, with s = sqrt(fma(-4a, c, bb)) (one rounding of the
+// contract's exact discriminant, which is built on the ROUNDED product bb = b*b).  For spheres that pass the flags below, |T/(2a*t_exact) - 1| < 2^-21.  The two
+// smallest estimates are kept.
+// Phase 2: if the runner-up is more than 2^-18 (relative) behind, the nearest sphere is decided
+// and only that one runs the FP64 path (bit-identical t).  A lane is "ambiguous" -- and redoes
+// the literal loop over all spheres -- when the two best are closer than that, when a root is
+// too close to zero to classify its sign, when the hit is near the 1e6 acceptance
+// limit (pathtrace.cu:94), or when anything is non-finite.  Ambiguous lanes are rare
+// (box edges, ~1e-5 of rays) and cost only time, never a different result.
+__device__ __forceinline__ bool intersect_scene_screened(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                         float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;  // 1 + 2^-16
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+PT_UNROLL(PT_SCREEN_UNROLL)
+  for (int i = 0; i < n; i++) {
+    const float4 g = sc.geom[i];
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - g.w;
+    const float bb = b * b;
+    const float a4c = rc.a4 * c;
+    const float det = bb - a4c;
+    const float dacc = fmaf(-rc.a4, c, bb);
+    const float s = __builtin_amdgcn_sqrtf(fmaxf(dacc, 0.0f));
+    const float q = b + copysignf(s, b);
+    const float TA = -q;  // = -b - sign(b)*s: the contract's own expression, no cancellation
+    // the other root -b + sign(b)*s = (s*s - b*b)/q, and s*s = bb - 4ac with the ROUNDED bb of the
+    // contract: s*s - b*b = -(4ac + (b*b - bb)); e = b*b - bb is exact in one fma.
+    const float e = fmaf(b, b, -bb);
+    const float num = a4c + e;
+    const float TB = -num * __builtin_amdgcn_rcpf(q);
+    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+    const float T = lo > 0.0f ? lo : hi;
+    const bool real = det >= 0.0f && dacc >= 0.0f;
+    const bool ok = real && T > 0.0f && T < Tlim_hi;
+    // the sign of the cancelling root is the sign of num: reliable unless num is within its own
+    // rounding error (2^-24 |4ac|) of zero; NaN/inf -> unsure
+    unsure = unsure || (real && !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f && fabsf(T) < INF));
+    const float Te = ok ? T : INF;
+    const bool c1 = Te < T1, c2 = Te < T2;
+    T2 = c1 ? T1 : (c2 ? Te : T2);
+    i1 = c1 ? i : i1;
+    T1 = c1 ? Te : T1;
+  }
+  bool ambiguous = unsure || (T1 < INF && (T2 <= T1 * 1.0000038f || T1 >= Tlim * 0.99998f));
+  bool hit = false;
+  if (!ambiguous && T1 < INF) {
+    float t;
+    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+      hit = true;
+      t_hit = t;
+      idx = i1;
+    } else {
+      ambiguous = true;  // the estimate and the exact test disagree: let the literal loop decide
+    }
+  }
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
+// Variant 3: the same screen with the float part evaluated for TWO spheres per instruction
+// (v_pk_add/mul/fma_f32).  A plain FP32 VALU op and an FP64 op both issue at 4 cycles per
+// wave64 on gfx950; only packed FP32 doubles that, and the kernel is VALU-issue bound.  The
+// packed operations are the contract's own mul/add sequence (no contraction), so det, b, c
+// are bit-identical to the scalar path.  Flags are combined without short-circuit branches.
+__device__ __forceinline__ void screen_tail(float b, float a4c, float det, float dacc, float num, float TA, float TB,
+                                            float Tlim_hi, int i, float& T1, float& T2, int& i1, bool& unsure) {
+  const float INF = __builtin_inff();
+  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+  const float T = lo > 0.0f ? lo : hi;
+  const bool real = (det >= 0.0f) & (dacc >= 0.0f);
+  const bool ok = real & (T > 0.0f) & (T < Tlim_hi);
+  unsure = unsure | (real & !((fabsf(num) > fabsf(a4c) * 4.7683716e-07f) & (fabsf(T) < INF)));
+  const float Te = ok ? T : INF;
+  const bool c1 = Te < T1, c2 = Te < T2;
+  T2 = c1 ? T1 : (c2 ? Te : T2);
+  i1 = c1 ? i : i1;
+  T1 = c1 ? Te : T1;
+  (void)b;
+}
+
+__device__ __forceinline__ bool intersect_scene_screened_pk(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                            float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;  // 1 + 2^-16
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+  const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+  const v2f a4 = {rc.a4, rc.a4};
+  const int npairs = (n + 1) >> 1;
+  for (int p = 0; p < npairs; p++) {
+    const float4 A = sc.pair[2 * p], B = sc.pair[2 * p + 1];
+    const v2f offx = ox - v2f{A.x, A.y}, offy = oy - v2f{A.z, A.w}, offz = oz - v2f{B.x, B.y};
+    const v2f dd = dx * offx + dy * offy + dz * offz;
+    const v2f b = dd + dd;
+    const v2f c = (offx * offx + offy * offy + offz * offz) - v2f{B.z, B.w};
+    const v2f bb = b * b;
+    const v2f a4c = a4 * c;
+    const v2f det = bb - a4c;
+    const v2f dacc = __builtin_elementwise_fma(-a4, c, bb);
+    const v2f e = __builtin_elementwise_fma(b, b, -bb);
+    const v2f num = a4c + e;
+    const v2f s = {__builtin_amdgcn_sqrtf(fmaxf(dacc.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(dacc.y, 0.0f))};
+    const v2f q = b + v2f{copysignf(s.x, b.x), copysignf(s.y, b.y)};
+    const v2f r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+    const v2f TA = -q;
+    const v2f TB = -num * r;
+    screen_tail(b.x, a4c.x, det.x, dacc.x, num.x, TA.x, TB.x, Tlim_hi, 2 * p, T1, T2, i1, unsure);
+    screen_tail(b.y, a4c.y, det.y, dacc.y, num.y, TA.y, TB.y, Tlim_hi, 2 * p + 1, T1, T2, i1, unsure);
+  }
+  bool ambiguous = unsure | ((T1 < INF) & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
+  bool hit = false;
+  if (!ambiguous && T1 < INF) {
+    float t;
+    if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+      hit = true;
+      t_hit = t;
+      idx = i1;
+    } else {
+      ambiguous = true;
+    }
+  }
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
+// Variant 5: the screen of variant 2 as straight-line code (no branches in the loop body, so
+// unrolled iterations interleave) with fewer and cheaper instructions:
+//  * validity (det >= 0, disc >= 0, T > 0) is read off the sign bits: a negative det, dacc or T
+//    puts the candidate's key above every valid key;
+//  * candidates are ranked as unsigned keys = float bits of T with the low ceil(log2 n) bits
+//    replaced by the sphere index, so best / second best are one v_min_u32 + one v_med3_u32.
+//    Truncating T costs 2^-(23-bits) of precision, which the ambiguity margin absorbs.
+// A T of +0, a hit beyond the 1e6 limit or any estimate/exact disagreement is caught by the
+// exact test of phase 2, which sends the lane to the literal loop.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;  // median of three unsigned values in one instruction (no builtin for the integer form)
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+struct ScreenState {
+  uint32_t k1, k2;
+  bool unsure;
+};
+
+__device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
+                                              ScreenState& st) {
+  const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  const float b = 2.0f * dot(d, off);
+  const float c = dot(off, off) - g.w;
+  const float bb = b * b;
+  const float a4c = rc.a4 * c;
+  const float det = bb - a4c;
+  const float dacc = fmaf(-rc.a4, c, bb);          // one rounding of the contract's exact discriminant bb - 4ac
+  const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the sign bit of dacc rejects it below
+  const float q = b + copysignf(s, b);             // |b| + s with b's sign: no cancellation
+  const float e = fmaf(b, b, -bb);                 // b*b - bb exactly: the rounding error of the contract's bb
+  const float num = a4c + e;
+  const float TA = -q;                             // root -b - sign(b) s (x 2a)
+  const float TB = -num * __builtin_amdgcn_rcpf(q);  // root -b + sign(b) s = -(4ac + (b*b - bb)) / q (x 2a)
+  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+  const float T = lo > 0.0f ? lo : hi;             // the reference's choice: tNear if positive, else tFar
+  const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
+  const uint32_t w = dd | __float_as_uint(T);
+  uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
+  key = (key & ~imask) | (uint32_t)i;
+  st.unsure = st.unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+  st.k2 = umed3(st.k1, st.k2, key);
+  st.k1 = st.k1 < key ? st.k1 : key;
+}
+
+template <bool NB>
+__device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                              float& t_hit, int& idx) {
+  if (n <= 0) return false;
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const uint32_t lim_hi_bits = __float_as_uint(Tlim * 1.0000153f);
+  const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));  // index bits (wave-uniform)
+  const uint32_t imask = (1u << ib) - 1u;
+  const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
+  ScreenState st{0xFFFFFFFFu, 0xFFFFFFFFu, false};
+  auto screen = [&](const float4 g, int i) { screen_sphere(g, i, o, d, rc, imask, st); };
+  // Manually unrolled by three (hipcc does not runtime-unroll this loop on request): the three
+  // LDS reads are issued together and the three dependency chains interleave, which is what
+  // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
+  int i = 0;
+#if PT_UNROLL_NINE
+  if (n == 9) {  // the reference's scene size (Scene.h:23): constant LDS offsets and indices, no loop state
+#pragma unroll
+    for (int u = 0; u < 9; u++) screen(sc.geom[u], u);
+    i = 9;
+  }
+#endif
+  for (; i + 3 <= n; i += 3) {
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2];
+    screen(g0, i);
+    screen(g1, i + 1);
+    screen(g2, i + 2);
+  }
+  for (; i < n; i++) screen(sc.geom[i], i);
+  const uint32_t k1 = st.k1, k2 = st.k2;
+  const bool has = k1 < lim_hi_bits;
+  const float T1 = __uint_as_float(k1 & ~imask);
+  bool ambiguous = st.unsure | (has & (((k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
+  bool hit = false;
+  if constexpr (NB) {
+    // straight-line: evaluate the winner unconditionally, decide afterwards
+    const int i1 = (int)(k1 & imask);
+    float t;
+    bool bad = false;
+    const bool real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
+    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    ambiguous = ambiguous | (has & (bad | !good));
+    hit = has & good;
+    t_hit = t;
+    idx = i1;
+#ifndef PT_TIMING_ONLY_NO_ISECT_REDO
+    if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+#endif
+    return hit;
+  } else {
+    if (!ambiguous && has) {
+      const int i1 = (int)(k1 & imask);
+      float t;
+      if (intersect_sphere_v1(o, d, rc, sc.geom[i1], t) && t > 0.0f && t < 1000000.0f) {
+        hit = true;
+        t_hit = t;
+        idx = i1;
+      } else {
+        ambiguous = true;
+      }
+    }
+    if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+    return hit;
+  }
+}
+
+// Many-sphere scenes (BASELINE config 4): most spheres are missed by every lane of the wave, so the
+// screen first runs only the contract's float part and skips the rest of the iteration with one
+// wave-uniform branch when no lane has a real intersection.  Candidates keep full float precision
+// (index tracked separately), the winner alone runs the FP64 path.
+__device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
+                                                               float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim_hi = Tlim * 1.0000153f;
+  float T1 = INF, T2 = INF;
+  int i1 = 0;
+  bool unsure = false;
+  struct Head {
+    float b, a4c, bb, dacc;
+    uint32_t dd;
+  };
+  auto head = [&](const float4 g) {  // the contract's float part: decides det >= 0 exactly
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    Head h;
+    h.b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - g.w;
+    h.bb = h.b * h.b;
+    h.a4c = rc.a4 * c;
+    const float det = h.bb - h.a4c;
+    h.dacc = fmaf(-rc.a4, c, h.bb);
+    h.dd = __float_as_uint(det) | __float_as_uint(h.dacc);
+    return h;
+  };
+  auto tail = [&](const Head& h, int i) {  // estimate + ranking, only when some lane really hits
+    if (__builtin_amdgcn_ballot_w64((int)h.dd >= 0) == 0) return;
+    const float s = __builtin_amdgcn_sqrtf(h.dacc);
+    const float q = h.b + copysignf(s, h.b);
+    const float e = fmaf(h.b, h.b, -h.bb);
+    const float num = h.a4c + e;
+    const float TA = -q;
+    const float TB = -num * __builtin_amdgcn_rcpf(q);
+    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
+    const float T = lo > 0.0f ? lo : hi;
+    const bool ok = ((int)(h.dd | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
+    unsure = unsure | (((int)h.dd >= 0) & !(fabsf(num) > fabsf(h.a4c) * 4.7683716e-07f));
+    const float Te = ok ? T : INF;
+    const bool c1 = Te < T1, c2 = Te < T2;
+    T2 = c1 ? T1 : (c2 ? Te : T2);
+    i1 = c1 ? i : i1;
+    T1 = c1 ? Te : T1;
+  };
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {  // four LDS reads and four float parts in flight, then the conditional tails
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2], g3 = sc.geom[i + 3];
+    const Head h0 = head(g0), h1 = head(g1), h2 = head(g2), h3 = head(g3);
+    tail(h0, i);
+    tail(h1, i + 1);
+    tail(h2, i + 2);
+    tail(h3, i + 3);
+  }
+  for (; i < n; i++) tail(head(sc.geom[i]), i);
+  const bool has = T1 < INF;
+  bool ambiguous = unsure | (has & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
+  float t;
+  bool bad = false;
+  const bool real = intersect_sphere_nb(o, d, rc, sc.geom[i1], t, bad);
+  const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+  ambiguous = ambiguous | (has & (bad | !good));
+  t_hit = t;
+  idx = i1;
+  bool hit = has & good;
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+  return hit;
+}
+
+template <int VAR>
+__device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+  const RayConst rc = make_ray_const(d);
+  if constexpr (VAR >= 5) {
+    // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
+    // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
+    // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
+    if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+    if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
+    return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
+  }
+  if constexpr (VAR == 3)
+    return intersect_scene_screened_pk(sc, n, o, d, rc, t_hit, idx);
+  else if constexpr (VAR == 2 || VAR == 4)
+    return intersect_scene_screened(sc, n, o, d, rc, t_hit, idx);
+  else
+    return intersect_scene_loop<VAR>(sc, n, o, d, rc, t_hit, idx);
+}
+
+// nearest hit for P rays at once; same decisions as intersect_scene_screened_keys<true>
+template <int P>
+__device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const F3 (&o)[P], const F3 (&d)[P],
+                                                bool (&hit)[P], float (&t_hit)[P], int (&idx)[P]) {
+  RayConst rc[P];
+  ScreenState st[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    rc[p] = make_ray_const(d[p]);
+    st[p] = ScreenState{0xFFFFFFFFu, 0xFFFFFFFFu, false};
+    hit[p] = false;
+  }
+  if (n <= 0) return;
+  if (n > PT_SCREEN_MAX_SPHERES) {
+#pragma unroll
+    for (int p = 0; p < P; p++) hit[p] = intersect_scene_loop<1>(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
+    return;
+  }
+  const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));
+  const uint32_t imask = (1u << ib) - 1u;
+  const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);
+  int i = 0;
+#if PT_UNROLL_NINE
+  if (P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
+#pragma unroll
+    for (int u = 0; u < 9; u++) screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
+    i = 9;
+  }
+#endif
+  for (; i + 2 <= n; i += 2) {
+    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      screen_sphere(g0, i, o[p], d[p], rc[p], imask, st[p]);
+      screen_sphere(g1, i + 1, o[p], d[p], rc[p], imask, st[p]);
+    }
+  }
+  for (; i < n; i++) {
+    const float4 g = sc.geom[i];
+#pragma unroll
+    for (int p = 0; p < P; p++) screen_sphere(g, i, o[p], d[p], rc[p], imask, st[p]);
+  }
+  bool ambiguous[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    const float Tlim = 1000000.0f * (2.0f * rc[p].a);
+    const bool has = st[p].k1 < __float_as_uint(Tlim * 1.0000153f);
+    const float T1 = __uint_as_float(st[p].k1 & ~imask);
+    ambiguous[p] = st[p].unsure | (has & (((st[p].k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
+    const int i1 = (int)(st[p].k1 & imask);
+    float t;
+    bool bad = false;
+    const bool real = intersect_sphere_nb(o[p], d[p], rc[p], sc.geom[has ? i1 : 0], t, bad);
+    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    ambiguous[p] = ambiguous[p] | (has & (bad | !good));
+    hit[p] = has & good;
+    t_hit[p] = t;
+    idx[p] = i1;
+  }
+#pragma unroll
+  for (int p = 0; p < P; p++)
+    if (__builtin_expect(ambiguous[p], 0)) hit[p] = intersect_scene_loop<0>(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
+}
+
+}  // namespace pt

@@ -1,0 +1,206 @@
+// pt_trace.h -- one path (src/pathtrace.cu:150-201): accumulating form (trace_ray) and the
+// result-returning lockstep form (trace_paths + accumulate_path) used by variants 7 and 8.
+#pragma once
+#include "pt_intersect.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+// trace_ray: src/pathtrace.cu:150-201
+template <int RNG, int VAR>
+__device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
+                                          Welford (&var)[4], int max_bounces) {
+  F3 color = mk3(0.0f, 0.0f, 0.0f);
+  F3 mask = mk3(1.0f, 1.0f, 1.0f);
+  auto bounce = [&](int n) -> bool {  // one iteration of the loop at :155; false = the ray left the scene
+    float t = 0.0f;
+    int idx = 0;
+    if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
+      L.color = L.color + color;
+      return false;
+    }
+    const float4 g = sc.geom[idx];
+    const float4 m0 = sc.mat0[idx];
+    const float4 m1 = sc.mat1[idx];
+    const F3 emis = mk3(m0.x, m0.y, m0.z);
+    const F3 scol = mk3(m0.w, m1.x, m1.y);
+    F3 normal;
+    float u_az, u_el;
+    if constexpr (VAR >= 6) {
+      // whole geometric step speculatively with the cheap sequences, literal redo if any of them
+      // met an input outside its verified domain (never observed in the Cornell box)
+      rng.bounce(n, u_az, u_el);
+      bool bad = false;
+      BounceGeom bg = bounce_geometry<true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+#ifndef PT_TIMING_ONLY_NO_SHADE_REDO
+      if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+#endif
+      normal = bg.normal;
+      o = bg.o;
+      d = bg.d;
+    } else {
+    F3 pos = o + d * t;                                // :163
+    normal = pos - mk3(g.x, g.y, g.z);                 // :164
+    if constexpr (VAR >= 4) normal = normalize_fast(normal); else normal = normalize(normal);
+    if (!(dot(normal, d) < 0.0f)) normal = normal * -1.0f;  // :166
+    o = pos + normal * 0.05f;         // :178, PUSH_RAY_ORIGIN
+    rng.bounce(n, u_az, u_el);
+    if constexpr (VAR >= 4)
+      d = normalize_fast(cosine_weighted_fast(normal, u_az, u_el));  // :180
+    else
+      d = normalize(cosine_weighted(normal, u_az, u_el));
+    }
+    F3 me = mask * emis;
+    if (n == 0)  // :171-172
+      color = color + mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f));
+    else  // :174
+      color = color + me;
+    mask = mask * scol;               // :175
+    if (n == 0) {                     // :187-195
+      L.normal = L.normal + normal;
+      L.albedo = L.albedo + scol;
+      L.depth += t;
+      welford_update(var[1], luminance(normal));
+      welford_update(var[2], luminance(scol));
+      welford_update(var[3], t);
+    }
+    return true;
+  };
+#if PT_UNROLL_BOUNCES
+  if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
+#pragma unroll
+    for (int n = 0; n < 5; n++)
+      if (!bounce(n)) return;
+  } else
+#endif
+  {
+    for (int n = 0; n < max_bounces; n++)
+      if (!bounce(n)) return;
+  }
+  L.color = L.color + color;                    // :198
+  welford_update(var[0], luminance(color));     // :200
+}
+
+// ---- variant 7: two samples of a pixel in lockstep ---------------------------------------------
+// A lane traces samples 2k and 2k+1 together, so every stage has two independent dependency
+// chains to interleave: what a small row tile (multi-GPU, ~2 waves per SIMD) needs, since there
+// a lone wave is latency-bound.  Sample order is part of the contract (sequential generator,
+// sequential float sums and Welford updates), so:
+//  * xorwow: sample B's generator is A's advanced by the 2 + 2*max_bounces draws a non-escaping
+//    path consumes (speculation).  If A escapes early the speculation was wrong and B is retraced
+//    alone from A's true final state -- never in a closed scene, at worst 1.5x work in an open one;
+//  * philox is counter-based: no speculation;
+//  * results are accumulated strictly A then B, with the reference's own expressions.
+struct PathResult {
+  F3 color, normal0, albedo0;
+  float t0;
+  bool hit0;     // the primary ray hit something: first-bounce features exist (:187-195)
+  bool escaped;  // the path left the scene: no colour-variance update (:157-161)
+};
+
+// trace_ray (src/pathtrace.cu:150-201) for P paths in lockstep; results are returned, not accumulated
+template <int RNG, int P>
+__device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds& sc, int nsph, F3 (&o)[P], F3 (&d)[P],
+                                            Rng<RNG> (&rng)[P], int max_bounces) {
+  F3 color[P], mask[P];
+  bool alive[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    color[p] = mk3(0.0f, 0.0f, 0.0f);
+    mask[p] = mk3(1.0f, 1.0f, 1.0f);
+    alive[p] = true;
+    res[p].hit0 = false;
+    res[p].escaped = false;
+    res[p].normal0 = mk3(0.0f, 0.0f, 0.0f);
+    res[p].albedo0 = mk3(0.0f, 0.0f, 0.0f);
+    res[p].t0 = 0.0f;
+  }
+  auto bounce = [&](int n) -> bool {  // false = every path of this lane has left the scene
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < P; p++) any = any | alive[p];
+    if (!any) return false;
+    bool hit[P];
+    float t[P];
+    int idx[P];
+    intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
+    // stage 1 (straight-line for all paths, so their chains interleave): materials, draws, fast geometry
+    F3 centre[P], emis[P], scol[P];
+    float u_az[P], u_el[P];
+    BounceGeom bg[P];
+    bool bad[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const bool was_alive = alive[p];
+      res[p].escaped = res[p].escaped | (was_alive & !hit[p]);  // :157-161
+      alive[p] = was_alive & hit[p];
+      const int ix = alive[p] ? idx[p] : 0;
+      const float4 g = sc.geom[ix];
+      const float4 m0 = sc.mat0[ix];
+      const float4 m1 = sc.mat1[ix];
+      centre[p] = mk3(g.x, g.y, g.z);
+      emis[p] = mk3(m0.x, m0.y, m0.z);
+      scol[p] = mk3(m0.w, m1.x, m1.y);
+      u_az[p] = 0.5f;
+      u_el[p] = 0.5f;
+      if (alive[p]) rng[p].bounce(n, u_az[p], u_el[p]);  // a dead path draws nothing
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      bad[p] = false;
+      bg[p] = bounce_geometry<true>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p]);
+    }
+    // stage 2: rare literal redo, then commit
+#pragma unroll
+    for (int p = 0; p < P; p++)
+      if (__builtin_expect(bad[p] & alive[p], 0)) bg[p] = bounce_geometry<false>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p]);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const F3 me = mask[p] * emis[p];
+      const F3 add = (n == 0) ? mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f)) : me;  // :171-174
+      if (alive[p]) {
+        color[p] = color[p] + add;
+        mask[p] = mask[p] * scol[p];  // :175
+        o[p] = bg[p].o;
+        d[p] = bg[p].d;
+        if (n == 0) {  // :187-195 (accumulated by the caller)
+          res[p].hit0 = true;
+          res[p].normal0 = bg[p].normal;
+          res[p].albedo0 = scol[p];
+          res[p].t0 = t[p];
+        }
+      }
+    }
+    return true;
+  };
+#if PT_UNROLL_BOUNCES
+  if (P == 1 && max_bounces == 5) {
+#pragma unroll
+    for (int n = 0; n < 5; n++)
+      if (!bounce(n)) break;
+  } else
+#endif
+  {
+    for (int n = 0; n < max_bounces; n++)
+      if (!bounce(n)) break;
+  }
+#pragma unroll
+  for (int p = 0; p < P; p++) res[p].color = color[p];
+}
+
+// what trace_ray adds to the pixel's accumulators for one finished path, in the reference's order
+__device__ __forceinline__ void accumulate_path(TraceOutput& L, Welford (&var)[4], const PathResult& r) {
+  if (r.hit0) {  // :187-195
+    L.normal = L.normal + r.normal0;
+    L.albedo = L.albedo + r.albedo0;
+    L.depth += r.t0;
+    welford_update(var[1], luminance(r.normal0));
+    welford_update(var[2], luminance(r.albedo0));
+    welford_update(var[3], r.t0);
+  }
+  L.color = L.color + r.color;                                   // :159 / :198
+  if (!r.escaped) welford_update(var[0], luminance(r.color));    // :200
+}
+
+}  // namespace pt
