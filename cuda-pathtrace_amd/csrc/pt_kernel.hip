@@ -40,6 +40,8 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   const F3 B0 = mk3(a.basis[0], a.basis[1], a.basis[2]), B1 = mk3(a.basis[3], a.basis[4], a.basis[5]);
   const F3 B2 = mk3(a.basis[6], a.basis[7], a.basis[8]), B3 = mk3(a.basis[9], a.basis[10], a.basis[11]);
   const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
+  const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
+  const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
 
   Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
   TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
@@ -52,8 +54,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
       sx += jx * 1.0f - 0.5f;
       sy += jy * 1.0f - 0.5f;
     }
-    sx /= (float)a.height;  // contract C7
-    sy /= (float)a.width;
+    if (pow2_image) {  // x / 2^k == x * 2^-k exactly: spares two correctly rounded divisions per sample
+      sx *= inv_h;
+      sy *= inv_w;
+    } else {
+      sx /= (float)a.height;  // contract C7
+      sy /= (float)a.width;
+    }
     dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
   };
 
@@ -188,6 +195,8 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   const F3 B0 = mk3(a.basis[0], a.basis[1], a.basis[2]), B1 = mk3(a.basis[3], a.basis[4], a.basis[5]);
   const F3 B2 = mk3(a.basis[6], a.basis[7], a.basis[8]), B3 = mk3(a.basis[9], a.basis[10], a.basis[11]);
   const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
+  const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
+  const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
 
   float sum0 = 0.0f, sum1 = 0.0f, sum2 = 0.0f;  // this lane's feature sums (depth uses sum0 only)
   Welford w{0, 0.0f, 0.0f};
@@ -211,8 +220,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
         sx += jx * 1.0f - 0.5f;
         sy += jy * 1.0f - 0.5f;
       }
-      sx /= (float)a.height;
-      sy /= (float)a.width;
+      if (pow2_image) {
+        sx *= inv_h;
+        sy *= inv_w;
+      } else {
+        sx /= (float)a.height;
+        sy /= (float)a.width;
+      }
       F3 o1[1] = {eye}, d1[1] = {lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx)};
       trace_paths<RNG, 1>(res, sc, a.n_spheres, o1, d1, g, a.max_bounces);
       rng = g[0];
