@@ -95,6 +95,7 @@ ABI = {
     "pt_scene_cornell": (ctypes.c_int, [_vp]),
     "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
     "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
+    "pt_display_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "pt_debug_unary_map": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "pt_debug_unary_compare": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
@@ -160,6 +161,20 @@ def device_info():
     khz = ctypes.c_int(0)
     check(lib.pt_device_info(name, 256, ctypes.byref(cus), ctypes.byref(khz)))
     return {"name": name.value.decode(), "compute_units": cus.value, "clock_khz": khz.value}
+
+
+def display_pack(frame):
+    """pt_display_pack on a host [rows][cols][14] frame (uploads, packs on the GPU, downloads)."""
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    h, w = frame.shape[0], frame.shape[1]
+    din, dout = DeviceBuffer(frame.nbytes).upload(frame), DeviceBuffer(h * w * 12)
+    try:
+        check(lib.pt_display_pack(din.ptr, w, h, dout.ptr, None))
+        check(lib.pt_device_synchronize())
+        return dout.download(np.float32, (h, w, 3))
+    finally:
+        din.free()
+        dout.free()
 
 
 def unary_map(fn, x):

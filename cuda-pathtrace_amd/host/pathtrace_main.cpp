@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "Camera.h"
+#include "Denoiser.h"
 #include "OutputBuffer.h"
 #include "Renderer.h"
 #include "Scene.h"
@@ -45,6 +46,7 @@ static void usage() {
                "  --spheres arg                 render a seeded random scene of N spheres\n"
                "  --frames arg                  render N frames back to back (headless interactive loop)\n"
                "  --poses arg                   fly-through: file with one 'x y z yaw pitch' line per frame\n"
+               "  --preview arg                 also write the display-packed frame (Denoiser) as a binary PPM\n"
             << std::endl;
 }
 
@@ -60,7 +62,7 @@ int main(int argc, const char** argv) {
   std::string outputName = "output/out";
   std::string rng = "xorwow";
   int maxBounces = 5, nSpheres = 0, frames = 1;
-  std::string posesFile;
+  std::string posesFile, previewFile;
 
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -91,6 +93,7 @@ int main(int argc, const char** argv) {
     else if (a == "--spheres") nSpheres = atoi(value("--spheres"));
     else if (a == "--frames") frames = atoi(value("--frames"));
     else if (a == "--poses") posesFile = value("--poses");
+    else if (a == "--preview") previewFile = value("--preview");
     else {
       std::cerr << "ERROR: unrecognised option '" << a << "'" << std::endl << std::endl;
       usage();
@@ -169,6 +172,29 @@ int main(int argc, const char** argv) {
   }
   std::cout << "Render completed in " << renderTime << "ms (" << 1000.0f / renderTime << " fps)" << std::endl;
   std::cout << std::endl;
+  if (!previewFile.empty()) {
+    // what the interactive mode would put on screen (main.cu:175-176): Denoiser packs the colour
+    // channels to RGBA8 point sprites; here they are unpacked into a PPM instead of drawn with GL
+    Denoiser denoiser(width, height, threadsPerBlock);
+    void* d_vertices = NULL;
+    gpuErrchk(pt_malloc(&d_vertices, (size_t)width * height * 3 * sizeof(float)));
+    denoiser.Denoise(d_buffer, static_cast<float*>(d_vertices));
+    std::vector<float> vertices((size_t)width * height * 3);
+    gpuErrchk(pt_memcpy_d2h(vertices.data(), d_vertices, vertices.size() * sizeof(float)));
+    gpuErrchk(pt_free(d_vertices));
+    FILE* f = fopen(previewFile.c_str(), "wb");
+    if (!f) {
+      std::cerr << "ERROR: cannot write " << previewFile << std::endl;
+      return 1;
+    }
+    fprintf(f, "P6\n%d %d\n255\n", width, height);
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+      unsigned char rgba[4];
+      memcpy(rgba, &vertices[3 * i + 2], 4);
+      fwrite(rgba, 1, 3, f);
+    }
+    fclose(f);
+  }
   // save results (main.cu:186-192)
   OutputBuffer buffer(width, height);
   buffer.AllocateCPU();

@@ -146,6 +146,15 @@ typedef struct pt_kernel_info {
 } pt_kernel_info;
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info);
 
+/* ---- display packing ------------------------------------------------------------------- */
+/* Denoiser::Denoise -> denoise_kernel (include/Denoiser.h:29-52, src/denoise.cu:9-29): despite the
+ * name, the reference's "denoiser" only prepares the frame for its point-sprite display: colour
+ * clamped to [0,1] and packed as RGBA8 {r,g,b,1} into ONE float, written with the pixel's screen
+ * position as the vertex triple (col, width - row, packed) into d_vertices[row][col][3].  The
+ * OpenGL buffer the reference maps (GLPixelBuffer) is replaced by a plain device pointer.
+ * Asynchronous on hip_stream (NULL = default stream). */
+int pt_display_pack(const float* d_buffer, int width, int height, float* d_vertices, void* hip_stream);
+
 /* ---- host-side inputs of the path ------------------------------------------------------ */
 /* The 9 spheres Scene() hard-codes, include/Scene.h:26-34 (host array). */
 int pt_scene_cornell(pt_sphere out[9]);

@@ -64,6 +64,8 @@ def lib():
         L.pto_scene_cornell.argtypes = [ctypes.c_void_p]
         L.pto_camera_basis.restype = None
         L.pto_camera_basis.argtypes = [fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, fp]
+        L.pto_display_pack.restype = None
+        L.pto_display_pack.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
         L.pto_xorwow_init.restype = None
         L.pto_xorwow_init.argtypes = [ctypes.c_uint64, up]
         L.pto_xorwow_next.restype = ctypes.c_uint32
@@ -125,6 +127,15 @@ def render(width, height, spp, spheres=None, basis=None, eye=(50.0, 52.0, 295.6)
                           threads)
     if rc != 0:
         raise ValueError("pto_render: bad arguments")
+    return out
+
+
+def display_pack(img):
+    """denoise_kernel (src/denoise.cu:9-29) on a [rows][cols][14] frame -> [rows][cols][3] vertex triples."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape[0], img.shape[1]
+    out = np.zeros((h, w, 3), dtype=np.float32)
+    lib().pto_display_pack(_fp(img), w, h, _fp(out))
     return out
 
 

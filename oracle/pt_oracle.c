@@ -536,6 +536,27 @@ int pto_render(const pto_params* p, const pto_sphere* spheres, int n_spheres, co
   return 0;
 }
 
+/* denoise_kernel: src/denoise.cu:9-29.  min/max are CUDA's float overloads (fminf/fmaxf: a NaN
+ * operand yields the other one), colour*255.0 is a double product truncated to unsigned char. */
+void pto_display_pack(const float* in, int width, int height, float* out) {
+  for (int x = 0; x < height; x++)        /* x = row, :10 */
+    for (int y = 0; y < width; y++) {     /* y = col, :11 */
+      const float* px = in + ((size_t)x * width + y) * 14;           /* :16 */
+      unsigned char c[4];
+      for (int k = 0; k < 3; k++) {
+        float v = fminf(fmaxf(px[k], 0.0f), 1.0f);                   /* :18-20 */
+        c[k] = (unsigned char)((double)v * 255.0);                   /* :23 */
+      }
+      c[3] = 1;
+      float packed;
+      memcpy(&packed, c, 4);                                         /* union Color, :3-7 */
+      float* o = out + ((size_t)x * width + y) * 3;
+      o[0] = (float)y;                                               /* :26 */
+      o[1] = (float)(width - x);                                     /* :27 */
+      o[2] = packed;                                                 /* :28 */
+    }
+}
+
 void pto_setup_random(const pto_params* p, uint32_t* rng_state) {
   for (int row = p->row_begin; row < p->row_end; row++)
     for (int col = 0; col < p->width; col++) {

@@ -78,6 +78,10 @@ void pto_scene_cornell(pto_sphere out[9]);
 void pto_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int w, int h,
                       float basis_out[12]);
 
+/* denoise_kernel (src/denoise.cu:9-29): clamp colour to [0,1], pack RGBA8 {r,g,b,1} into one float,
+ * emit per pixel the vertex triple (col, width - row, packed).  in: [row][col][14], out: [row][col][3]. */
+void pto_display_pack(const float* in, int width, int height, float* out);
+
 /* Building blocks exposed for known-answer tests. */
 void pto_xorwow_init(uint64_t seed, uint32_t st[6]);
 uint32_t pto_xorwow_next(uint32_t st[6]);

@@ -238,3 +238,18 @@ def test_oracle_reproduces_committed_fixture(oracle, name):
     else:
         assert np.array_equal(img[g["rows"]].view(np.uint32), g["row_data"].view(np.uint32))
         assert np.allclose(img.reshape(-1, 14).mean(0, dtype=np.float64), g["means"], rtol=1e-12)
+
+
+def test_display_pack_known_answers(oracle):
+    """denoise_kernel restatement (src/denoise.cu:9-29): clamp, truncating *255.0, alpha byte 1,
+    vertex = (col, width - row, packed)."""
+    img = np.zeros((2, 3, 14), dtype=np.float32)
+    img[0, 0, :3] = [1.0, 0.5, 0.0]
+    img[0, 1, :3] = [2.0, -1.0, 0.999]
+    img[1, 2, :3] = [np.nan, 1.0 / 255.0, 254.999 / 255.0]
+    out = oracle.display_pack(img)
+    by = out[..., 2].copy().view(np.uint8).reshape(2, 3, 4)
+    assert list(by[0, 0]) == [255, 127, 0, 1]
+    assert list(by[0, 1]) == [255, 0, 254, 1]
+    assert list(by[1, 2]) == [0, 1, 254, 1]  # NaN clamps to 0 through fmaxf
+    assert out[1, 2, 0] == 2 and out[1, 2, 1] == 3 - 1

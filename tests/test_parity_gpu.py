@@ -398,3 +398,40 @@ def test_four_lane_kernel_keeps_generator_state_across_frames(pt, oracle, gpu, s
         assert_bit_exact(d_out.download(np.float32, (size, size, 14)), ref, f"{scene} spp {spp} frame {frame}")
         assert np.array_equal(r.get_rng_state(), st), f"{scene} spp {spp}: generator state after frame {frame}"
     r.destroy()
+
+
+def test_display_packer_matches_denoise_kernel(pt, oracle, gpu):
+    """pt_display_pack (the reference's Denoiser::Denoise / denoise_kernel, src/denoise.cu:9-29):
+    bit-exact vs the oracle on a rendered frame and on values that exercise the clamp
+    (negative, > 1, NaN, exact 1/255 steps)."""
+    basis = pt.camera_basis(width=64, height=64)
+    img, _ = pt.render_frame(64, 64, 4, basis=basis)
+    assert np.array_equal(pt.display_pack(img).view(np.uint32), oracle.display_pack(img).view(np.uint32))
+    rng = np.random.default_rng(3)
+    syn = rng.uniform(-0.5, 1.5, (33, 47, 14)).astype(np.float32)
+    syn[0, 0, :3] = [np.nan, -0.0, 1.0]
+    syn[1, :, 0] = np.arange(47, dtype=np.float32) / 255.0
+    syn[2, :, 1] = np.nextafter(np.arange(47, dtype=np.float32) / np.float32(255.0), np.float32(0))
+    a, b = pt.display_pack(syn), oracle.display_pack(syn)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert a[5, 7, 0] == 7 and a[5, 7, 1] == 47 - 5          # (col, width - row)
+    assert (a[..., 2].view(np.uint32) >> 24 == 1).all()      # alpha byte = 1
+
+
+def test_cli_preview_is_the_display_packed_frame(pt, oracle, gpu, tmp_path):
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    out, ppm = str(tmp_path / "f"), str(tmp_path / "f.ppm")
+    exe = os.path.join(ROOT, "cuda-pathtrace_amd", "pathtrace")
+    res = subprocess.run([exe, "--size", "32", "-s", "8", "--nobitmap", "-o", out, "--preview", ppm], capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n32 32\n255\n")
+    rgb = np.frombuffer(raw[len(b"P6\n32 32\n255\n"):], dtype=np.uint8).reshape(32, 32, 3)
+    ref = oracle.render(32, 32, 8, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=32, height=32))
+    want = oracle.display_pack(ref)[..., 2].copy().view(np.uint8).reshape(32, 32, 4)[..., :3]
+    assert np.array_equal(rgb, want)
