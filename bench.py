@@ -106,8 +106,14 @@ def main():
     torch.cuda.set_device(dev_index)
     pt.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # PT_BENCH_FORCE_DIST=1: initialise the process group even at world size 1 (exercises RCCL init,
+    # barrier and all-reduce on a single-GPU box)
+    use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -147,7 +153,7 @@ def main():
         for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
             f.wait_all(pending[slot])
             pending[slot] = []
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +169,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
 
     tmax = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_s = tmax[0].item(), tmax[1].item()
 
@@ -240,7 +246,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
