@@ -196,7 +196,9 @@ __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d,
   const float c = dot(off, off) - g.w;
   const float bb = b * b;
   const float a4c = rc.a4 * c;
-  const float det = bb - a4c;
+  // The contract's det = RN(bb - RN(4a*c)) is used only through its sign.  dacc below rounds the exact
+  // bb - 4a*c once; the two can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|, and such spheres are
+  // flagged unsure (|dacc| > 2^-21 |4ac| is required), so det itself need not be formed.
   const float dacc = fmaf(-rc.a4, c, bb);          // one rounding of the contract's exact discriminant bb - 4ac
   const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the sign bit of dacc rejects it below
   const float q = b + copysignf(s, b);             // |b| + s with b's sign: no cancellation
@@ -204,13 +206,17 @@ __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d,
   const float num = a4c + e;
   const float TA = -q;                             // root -b - sign(b) s (x 2a)
   const float TB = -num * __builtin_amdgcn_rcpf(q);  // root -b + sign(b) s = -(4ac + (b*b - bb)) / q (x 2a)
-  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
-  const float T = lo > 0.0f ? lo : hi;             // the reference's choice: tNear if positive, else tFar
-  const uint32_t dd = __float_as_uint(det) | __float_as_uint(dacc);
-  const uint32_t w = dd | __float_as_uint(T);
+  // The reference returns tNear if it is positive, else tFar.  Origin inside the sphere (c < 0): the roots
+  // have opposite signs, that is the larger one.  Outside (c > 0): same sign, the smaller one (if it is
+  // negative so is the other and the candidate is rejected either way).  One median with +-inf does both;
+  // c == 0 (or a root too close to 0 to classify) is flagged below.
+  const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));  // c < 0 ? +inf : -inf
+  const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
+  const uint32_t w = __float_as_uint(dacc) | __float_as_uint(T);
   uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
   key = (key & ~imask) | (uint32_t)i;
-  st.unsure = st.unsure | (((int)dd >= 0) & !(fabsf(num) > fabsf(a4c) * 4.7683716e-07f));
+  const float m = fabsf(a4c) * 4.7683716e-07f;  // 2^-21 |4ac| >> the rounding errors of num (and of det vs dacc)
+  st.unsure = st.unsure | !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m);
   st.k2 = umed3(st.k1, st.k2, key);
   st.k1 = st.k1 < key ? st.k1 : key;
 }

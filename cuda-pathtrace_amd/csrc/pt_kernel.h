@@ -25,7 +25,7 @@
 #define PT_KERNEL_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): let the scheduler spend registers on ILP
 #endif
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 1  // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
+#define PT_MIN_WAVES 4  // __launch_bounds__ 2nd argument: the register allocator must allow 4 waves per SIMD (<= 128 VGPRs)
 #endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the
