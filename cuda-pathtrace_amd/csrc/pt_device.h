@@ -213,7 +213,7 @@ __device__ __forceinline__ bool in_fast_range(float x) {
 #ifdef PT_TIMING_ONLY_NO_FALLBACKS  // never defined in a shipped build: upper bound of what the rare branches cost
   return true;
 #endif
-  return ((__float_as_uint(x) >> 23) - 27u) < 200u;  // sign clear and 2^-100 <= x < 2^100
+  return (__float_as_uint(x) - 0x0D800000u) < 0x64000000u;  // sign clear and 2^-100 <= x < 2^100 (exponent field 27..226)
 }
 
 __device__ __forceinline__ float sqrt_cr_f32(float x) {
@@ -362,7 +362,7 @@ __device__ __forceinline__ F3 normalize_nb(F3 v, bool& bad) { return v * inv_sqr
 
 __device__ __forceinline__ double sqrt_cr_nb(double x, bool& bad) {
   const uint32_t hi = (uint32_t)__double2hiint(x);
-  bad = bad | (((hi >> 20) - 423u) >= 1200u);
+  bad = bad | ((hi - (423u << 20)) >= (1200u << 20));  // sign set, exponent outside 2^-600..2^600, inf, NaN
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
   double h = y * 0.5;
@@ -381,7 +381,7 @@ __device__ __forceinline__ float quotient_to_float_nb(double num, const RayConst
   double rem = __builtin_fma(-q, rc.den, num);
   q = __builtin_fma(rem, rc.rden, q);
   const uint32_t lo = (uint32_t)__double2loint(q), hi = (uint32_t)__double2hiint(q);
-  bad = bad | (((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u) | ((((hi >> 20) & 0x7FFu) - 903u) >= 247u);
+  bad = bad | (((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u) | (((hi & 0x7FF00000u) - (903u << 20)) >= (247u << 20));
   return (float)q;
 }
 
