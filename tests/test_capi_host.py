@@ -92,3 +92,26 @@ def test_compute_fails_loudly_without_gpu(pt):
     assert e.value.code in (-2, -3) and "device" in str(e.value).lower()
     with pytest.raises(pt.PtError):
         pt.DeviceBuffer(1024)
+
+
+def test_header_is_strict_c99_and_example_fails_loudly_without_gpu(pt, tmp_path):
+    """INTEGRATION.md's raw C binding compiled with gcc -std=c99 -pedantic against include/ptcore.h."""
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = str(tmp_path / "abi_example")
+    libdir = os.path.join(ROOT, "cuda-pathtrace_amd")
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", ROOT, "-o", exe,
+                          os.path.join(ROOT, "tests", "cpp", "abi_example.c"), "-L", libdir, "-lptcore",
+                          "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True)
+    try:
+        have_gpu = pt.device_count() > 0
+    except pt.PtError:
+        have_gpu = False
+    if have_gpu:
+        assert run.returncode == 0 and run.stdout.startswith("ok ")
+    else:
+        assert run.returncode == 3 and "device" in run.stderr.lower()
