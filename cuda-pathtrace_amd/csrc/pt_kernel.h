@@ -8,12 +8,15 @@
 
 #define PT_BLOCK_THREADS 256
 #ifndef PT_SCREEN_UNROLL
-#define PT_SCREEN_UNROLL 9  // unroll factor of the screening loop (ILP at low occupancy)
+#define PT_SCREEN_UNROLL 9  // requested unroll of the variant-2/4 screening loop (hipcc ignores it for runtime trip counts)
 #endif
-#define PT_VARIANT_AUTO (-1)   // pt_renderer_opts_default(): variant 6, or 8 for small tiles (see pt_capi.hip)
-#define PT_DEFAULT_VARIANT 6  // what pt_renderer_opts_default() selects; 0 is the literal transcription
+// Kernel variants (all bit-identical): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
+// FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
+// lane, 8 four lanes per pixel.
+#define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
+#define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES
-#define PT_SCREEN_MAX_SPHERES 64  // variant 5 screens scenes up to this size, larger ones use the literal loop
+#define PT_SCREEN_MAX_SPHERES 64  // variants >= 5 use the key-based screen up to this size, the many-sphere screen above
 #endif
 #ifndef PT_UNROLL_BOUNCES
 #define PT_UNROLL_BOUNCES 1  // also emit a fully unrolled path for the reference's MAX_BOUNCES = 5 (+6 %)
