@@ -353,7 +353,8 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);
   info->variant = variant;
-  if (variant == 8) info->grid_blocks = (int)(((uint64_t)r->tile_pixels * 4 + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+  if (variant == 8 || variant == 9)
+    info->grid_blocks = (int)(((uint64_t)r->tile_pixels * (variant == 8 ? 4 : 2) + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;

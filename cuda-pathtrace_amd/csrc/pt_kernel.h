@@ -12,7 +12,7 @@
 #endif
 // Kernel variants (all bit-identical): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
 // FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
-// lane, 8 four lanes per pixel.
+// lane, 8 four lanes per pixel, 9 two lanes per pixel.
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES

@@ -155,11 +155,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
 //    continues in sequential mode (lane 0 traces, all four still accumulate) from that sample's true
 //    final state.  Never happens in a closed scene; in an open one the kernel degrades to 1/4
 //    efficiency for that pixel but stays exact.
-constexpr int kSplit = 4;
+// Variant 9 is the same kernel with TWO lanes per pixel, each owning two features: half the generator
+// skip-ahead, for tiles that are only moderately too small (about 4 one-lane waves per SIMD).
 constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
 
-template <int RNG>
+template <int RNG, int kSplit>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
+  constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
   const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
 
   const uint32_t gl = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
   const uint32_t tp = gl / kSplit;      // pixel index inside the tile
-  const int s = (int)(gl % kSplit);     // sample slot AND the feature this lane accumulates
+  const int s = (int)(gl % kSplit);     // sample slot; this lane accumulates features s*kOwn .. s*kOwn + kOwn - 1
   const bool active = tp < a.tile_pixels;
   const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
   const int col = (int)(tp % (uint32_t)a.width);
@@ -198,8 +200,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
   const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
 
-  float sum0 = 0.0f, sum1 = 0.0f, sum2 = 0.0f;  // this lane's feature sums (depth uses sum0 only)
-  Welford w{0, 0.0f, 0.0f};
+  float sum0[kOwn], sum1[kOwn], sum2[kOwn];  // this lane's feature sums (depth uses sum0 only)
+  Welford w[kOwn];
+#pragma unroll
+  for (int q = 0; q < kOwn; q++) {
+    sum0[q] = sum1[q] = sum2[q] = 0.0f;
+    w[q] = Welford{0, 0.0f, 0.0f};
+  }
   bool seq = false;  // group-uniform: sequential mode after a failed speculation
   int base = 0;      // group-uniform: first sample of the current round
 
@@ -253,17 +260,21 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
       const uint32_t fl = reinterpret_cast<const uint32_t*>(rj)[16];
       const bool valid = ((fl & 1u) != 0u) & !failed;
       const bool hit0 = (fl & 2u) != 0u, esc = (fl & 4u) != 0u;
-      const float4 v = *reinterpret_cast<const float4*>(rj + 4 * s);
-      const bool en_sum = valid & ((s == 0) | hit0);                 // colour is always added (:159,:198); AOVs on a first hit (:187-190)
-      const bool en_w = valid & ((s == 0) ? !esc : hit0);             // :200 / :192-194
-      sum0 = en_sum ? sum0 + v.x : sum0;
-      sum1 = en_sum ? sum1 + v.y : sum1;
-      sum2 = en_sum ? sum2 + v.z : sum2;
-      Welford wn = w;
-      welford_update(wn, v.w);
-      w.n = en_w ? wn.n : w.n;  // field-wise: a struct select would go through scratch
-      w.mean = en_w ? wn.mean : w.mean;
-      w.M2 = en_w ? wn.M2 : w.M2;
+#pragma unroll
+      for (int q = 0; q < kOwn; q++) {
+        const int f = s * kOwn + q;  // 0 colour, 1 normal, 2 albedo, 3 depth
+        const float4 v = *reinterpret_cast<const float4*>(rj + 4 * f);
+        const bool en_sum = valid & ((f == 0) | hit0);        // colour is always added (:159,:198); AOVs on a first hit (:187-190)
+        const bool en_w = valid & ((f == 0) ? !esc : hit0);    // :200 / :192-194
+        sum0[q] = en_sum ? sum0[q] + v.x : sum0[q];
+        sum1[q] = en_sum ? sum1[q] + v.y : sum1[q];
+        sum2[q] = en_sum ? sum2[q] + v.z : sum2[q];
+        Welford wn = w[q];
+        welford_update(wn, v.w);
+        w[q].n = en_w ? wn.n : w[q].n;  // field-wise: a struct select would go through scratch
+        w[q].mean = en_w ? wn.mean : w[q].mean;
+        w[q].M2 = en_w ? wn.M2 : w[q].M2;
+      }
       if constexpr (RNG == PT_RNG_XORWOW) {
         if (valid) {
           const uint32_t* ru = reinterpret_cast<const uint32_t*>(rj) + 17;
@@ -294,14 +305,18 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   if (active) {  // :234-254, each lane stores its feature
     const float fs = (float)a.spp;
     float* o = a.out + (size_t)tp * 14;
-    if (s < 3) {
-      o[3 * s + 0] = sum0 / fs;
-      o[3 * s + 1] = sum1 / fs;
-      o[3 * s + 2] = sum2 / fs;
-    } else {
-      o[9] = sum0 / fs;
+#pragma unroll
+    for (int q = 0; q < kOwn; q++) {
+      const int f = s * kOwn + q;
+      if (f < 3) {
+        o[3 * f + 0] = sum0[q] / fs;
+        o[3 * f + 1] = sum1[q] / fs;
+        o[3 * f + 2] = sum2[q] / fs;
+      } else {
+        o[9] = sum0[q] / fs;
+      }
+      o[10 + f] = welford_variance(w[q]);
     }
-    o[10 + s] = welford_variance(w);
     if constexpr (RNG == PT_RNG_XORWOW) {
       if (a.rng_state && s == 0) {  // :256
         uint32_t* p = a.rng_state + (size_t)tp * 6;
@@ -353,36 +368,38 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
     case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
     case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
-    case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX> : pt::pixel_kernel_split<PT_RNG_XORWOW>;
+    case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4>;
+    case 9: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 9; }
+int pt_kernel_num_variants(void) { return 10; }
 
 const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
-  return variant == 8 ? split_lds_bytes(n_spheres) : scene_lds_bytes(n_spheres);
+  return (variant == 8 || variant == 9) ? split_lds_bytes(n_spheres) : scene_lds_bytes(n_spheres);
 }
 
 int pt_kernel_max_spheres(int variant) {
-  if (variant == 8)
+  if (variant == 8 || variant == 9)
     return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float)) / (4 * sizeof(float4))) - 1;
   return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float)) / (4 * sizeof(float4))) - 1;
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
-  if (variant == 8) {
+  if (variant == 8 || variant == 9) {
+    const int split = variant == 8 ? 4 : 2;
     PixelKernelArgs b = a;
     b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres);
     const size_t lds = split_lds_bytes(a.n_spheres);
-    pixel_kernel_fn fs = rng_mode == PT_RNG_PHILOX ? pt::pixel_kernel_split<PT_RNG_PHILOX> : pt::pixel_kernel_split<PT_RNG_XORWOW>;
+    pixel_kernel_fn fs = select_kernel(rng_mode, variant);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)fs, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
       if (e != hipSuccess) return e;
     }
-    const uint64_t lanes = (uint64_t)a.tile_pixels * pt::kSplit;
+    const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)split;
     const unsigned grid = (unsigned)((lanes + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
     hipLaunchKernelGGL(fs, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, b);
     return hipGetLastError();
