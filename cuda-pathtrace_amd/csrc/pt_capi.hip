@@ -54,12 +54,19 @@ struct pt_renderer {
 // 4 waves/SIMD: 21.3 vs 22.3 ms, 2 waves/SIMD: 11.3 vs 12.7 ms, 8 and more: variant 6 wins).
 #define PT_SPLIT_MAX_WAVES_PER_SIMD 6
 
-static int effective_variant(pt_renderer* r) {
+static int effective_variant(pt_renderer* r, int n_spheres) {
   if (!r->auto_variant) return r->opts.variant;
   if (r->fail_pending && hipEventQuery(r->ev_fail) == hipSuccess) {
     r->fail_pending = false;
     if (*r->h_fail > r->tile_pixels / 50u) r->spec_ok = false;  // > 2 % of the pixels left speculative mode: an open scene
   }
+  // Many-sphere scenes: a bounce is n sphere tests, so neither the unrolled path of variant 6 nor more
+  // lanes per pixel matter; what does is that lanes whose path left the scene do not idle (open
+  // 1000-sphere scene: 35.5 -> 25.7 ms at 16 spp; closed scenes: equal to variant 6).
+  // A small closed tile still gains from four lanes per pixel (1/8 tile, 1000 spheres + walls: 17.9 vs 23.3 ms);
+  // the speculation feedback above sends an open scene back to variant 10.
+  if (n_spheres > PT_SCREEN_MAX_SPHERES)
+    return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
   // philox is counter-based: no skip-ahead, no speculation, and the four-lane kernel needs fewer
   // registers than variant 6 with the philox state (114 vs 131 VGPR) -- faster at every size measured
   if (r->opts.rng_mode == PT_RNG_PHILOX) return r->spp >= 4 ? 8 : PT_DEFAULT_VARIANT;
@@ -236,7 +243,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   if (!d_out && r->tile_pixels) return pt_fail(PT_EINVAL, "render: d_out is NULL");
   if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "render: bad scene (%d spheres)", n_spheres);
   if (!basis || !eye) return pt_fail(PT_EINVAL, "render: basis/eye is NULL");
-  const int variant = effective_variant(r);
+  const int variant = effective_variant(r, n_spheres);
   if (n_spheres > pt_kernel_max_spheres(variant))
     return pt_fail(PT_ELIMIT, "render: %d spheres exceed the LDS staging limit of %d", n_spheres,
                    pt_kernel_max_spheres(variant));
@@ -347,8 +354,8 @@ int pt_renderer_set_rng_state(pt_renderer* r, const uint32_t* h_state, size_t n_
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info) {
   if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
   hipFuncAttributes fa;
-  const int variant = effective_variant(r);
-  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant)));
+  const int variant = effective_variant(r, n_spheres);
+  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres)));
   info->block_threads = PT_BLOCK_THREADS;
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);

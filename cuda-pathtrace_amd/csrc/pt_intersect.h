@@ -391,7 +391,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   if (n <= 0) return;
   if (n > PT_SCREEN_MAX_SPHERES) {
 #pragma unroll
-    for (int p = 0; p < P; p++) hit[p] = intersect_scene_loop<1>(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
+    for (int p = 0; p < P; p++) hit[p] = intersect_scene_screened_large(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
     return;
   }
   const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));

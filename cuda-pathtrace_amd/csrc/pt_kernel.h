@@ -12,7 +12,7 @@
 #endif
 // Kernel variants (all bit-identical): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
 // FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
-// lane, 8 four lanes per pixel, 9 two lanes per pixel.
+// lane, 8 four lanes per pixel, 9 two lanes per pixel, 10 per-lane path regeneration (open scenes).
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES
@@ -56,7 +56,7 @@ struct PixelKernelArgs {
 };
 
 int pt_kernel_num_variants(void);
-const void* pt_kernel_symbol(int rng_mode, int variant);
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres);
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);

@@ -12,10 +12,12 @@
 namespace pt {
 
 // pixel_kernel: src/pathtrace.cu:203-257
-template <int RNG, int VAR>
+// LEAN selects the geometry-only LDS layout of many-sphere scenes (pt_scene_lds.h) at compile time, so the
+// 9-sphere kernels carry no trace of it.
+template <int RNG, int VAR, bool LEAN = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
-  const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
+  const SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;  // pixel index inside the tile
   const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
@@ -65,7 +67,40 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   };
 
   int i = active ? 0 : a.spp;  // inactive lanes trace nothing
-  if constexpr (VAR >= 7) {
+  if constexpr (VAR == 10) {
+    // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
+    // per lane): the sample loop and the bounce loop are flattened into one per-lane state machine, so a
+    // lane whose path left the scene starts its next sample at once instead of idling until the longest
+    // path of the wave has finished its bounces.  Every lane still executes exactly the reference's
+    // sequence for its pixel (same draws, same sums, same Welford updates, same order); only the
+    // alignment BETWEEN lanes changes.  Pays in open scenes, costs the unrolled path in closed ones.
+    int n = 0;  // depth of the current path; 0 = start a new sample
+    F3 o = eye, d = eye;
+    F3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);
+    while (i < a.spp) {
+      if (n == 0) {  // :219-229
+        rng.begin_sample((uint32_t)i);
+        primary_ray(rng, d);
+        o = eye;
+        color = mk3(0.0f, 0.0f, 0.0f);
+        mask = mk3(1.0f, 1.0f, 1.0f);
+      }
+      bool escaped = false;
+      if (n < a.max_bounces) {
+        escaped = !bounce_once<RNG, 6>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
+        n++;
+      }
+      if (escaped | (n >= a.max_bounces)) {
+        if (!escaped) {
+          L.color = L.color + color;                 // :198
+          welford_update(var[0], luminance(color));  // :200
+        }
+        i++;
+        n = 0;
+      }
+    }
+  }
+  if constexpr (VAR >= 7 && VAR != 10) {
     const int draws = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;  // consumed by a path that never escapes
     for (; i + 2 <= a.spp; i += 2) {
       Rng<RNG> g[2] = {rng, rng};
@@ -91,11 +126,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
       }
     }
   }
-  for (; i < a.spp; i++) {  // :219
-    rng.begin_sample((uint32_t)i);
-    F3 dir;
-    primary_ray(rng, dir);
-    trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+  if constexpr (VAR != 10) {
+    for (; i < a.spp; i++) {  // :219
+      rng.begin_sample((uint32_t)i);
+      F3 dir;
+      primary_ray(rng, dir);
+      trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+    }
   }
 
   const float fs = (float)a.spp;  // :234-237
@@ -107,7 +144,8 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u);
+  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
+                         !LEAN;  // the lean layout has no transpose slice (its frames take long enough not to care)
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
 #pragma unroll
@@ -159,11 +197,11 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
 // skip-ahead, for tiles that are only moderately too small (about 4 one-lane waves per SIMD).
 constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
 
-template <int RNG, int kSplit>
+template <int RNG, int kSplit, bool LEAN = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
-  const SceneLds sc = stage_scene(a.spheres, a.n_spheres, lds_scene);
+  const SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
   const int gbase = lane & ~(kSplit - 1);
@@ -347,18 +385,34 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 }  // namespace pt
 
 // ---- launchers (host) ---------------------------------------------------------------------
-static inline size_t scene_lds_f4(int n) { return (size_t)n * 3 + (size_t)((n + 1) / 2) * 2; }
-// scene image + one 64 x 14 float transpose slice per wave for the epilogue
-static inline size_t scene_lds_bytes(int n) { return scene_lds_f4(n) * sizeof(float4) + (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float); }
+// LDS layout of a launch (pt_scene_lds.h): many-sphere scenes keep only the geometry in LDS
+// (variants 6, 8 and 10 -- the ones the automatic policy uses -- are also built for that layout)
+static inline bool lds_lean(int n, int variant) { return n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10); }
+static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
+static inline size_t scene_lds_f4(int n, int variant) {
+  if (lds_lean(n, variant)) return (size_t)n;
+  return (size_t)n * 3 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);
+}
+// what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
+// split kernels' exchange records
+static inline size_t tail_lds_bytes(int n, int variant) {
+  if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
+  return lds_lean(n, variant) ? 0 : (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
+}
+static inline size_t scene_lds_bytes(int n, int variant) { return scene_lds_f4(n, variant) * sizeof(float4) + tail_lds_bytes(n, variant); }
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
-static inline size_t split_lds_bytes(int n) {
-  return scene_lds_f4(n) * sizeof(float4) + (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
-}
-
-static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
+static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean) {
   const bool philox = rng_mode == PT_RNG_PHILOX;
+  if (lean) {
+    switch (variant) {
+      case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, true>;
+      case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
+      case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
+      default: return nullptr;
+    }
+  }
   switch (variant) {
     case 0: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 0> : pt::pixel_kernel<PT_RNG_XORWOW, 0>;
     case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
@@ -370,50 +424,42 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant) {
     case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
     case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4>;
     case 9: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2>;
+    case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10> : pt::pixel_kernel<PT_RNG_XORWOW, 10>;
     default: return nullptr;
   }
 }
 
-int pt_kernel_num_variants(void) { return 10; }
+int pt_kernel_num_variants(void) { return 11; }
 
-const void* pt_kernel_symbol(int rng_mode, int variant) { return (const void*)select_kernel(rng_mode, variant); }
-
-size_t pt_kernel_lds_bytes(int n_spheres, int variant) {
-  return (variant == 8 || variant == 9) ? split_lds_bytes(n_spheres) : scene_lds_bytes(n_spheres);
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres) {
+  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant));
 }
 
+size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(n_spheres, variant); }
+
 int pt_kernel_max_spheres(int variant) {
-  if (variant == 8 || variant == 9)
-    return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float)) / (4 * sizeof(float4))) - 1;
-  return (int)((PT_LDS_BUDGET_BYTES - (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float)) / (4 * sizeof(float4))) - 1;
+  // variants with a lean build are bounded by 16 B per sphere, the others by their full image
+  const size_t tail = tail_lds_bytes(0, variant);
+  if (variant == 6 || variant == 10) return (int)(PT_LDS_BUDGET_BYTES / sizeof(float4));
+  if (variant == 8) return (int)((PT_LDS_BUDGET_BYTES - tail) / sizeof(float4));
+  if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (4 * sizeof(float4)));
+  return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
-  if (variant == 8 || variant == 9) {
-    const int split = variant == 8 ? 4 : 2;
-    PixelKernelArgs b = a;
-    b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres);
-    const size_t lds = split_lds_bytes(a.n_spheres);
-    pixel_kernel_fn fs = select_kernel(rng_mode, variant);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)fs, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
-      if (e != hipSuccess) return e;
-    }
-    const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)split;
-    const unsigned grid = (unsigned)((lanes + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-    hipLaunchKernelGGL(fs, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, b);
-    return hipGetLastError();
-  }
-  pixel_kernel_fn fn = select_kernel(rng_mode, variant);
+  pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant));
   if (!fn) return hipErrorInvalidValue;
-  const unsigned grid = (a.tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
   PixelKernelArgs b = a;
-  b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres);
-  if (scene_lds_bytes(a.n_spheres) > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
+  b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, variant);
+  const size_t lds = scene_lds_bytes(a.n_spheres, variant);
+  if (lds > PT_LDS_BUDGET_BYTES) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), scene_lds_bytes(a.n_spheres), stream, b);
+  const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);
+  const unsigned grid = (unsigned)((lanes + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, b);
   return hipGetLastError();
 }
 

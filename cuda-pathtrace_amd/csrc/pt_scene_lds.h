@@ -13,38 +13,71 @@ namespace pt {
 // LDS image of the scene: geometry and material split so the intersect loop touches
 // 16 B per sphere with a wave-uniform address (LDS broadcast read), and the shading step
 // gathers 32 B by the per-lane hit index.
+// Two layouts (chosen by the launcher, PixelKernelArgs::lds_layout):
+//  * full (scenes up to PT_SCREEN_MAX_SPHERES): geometry + materials (+ the paired image variant 3 reads);
+//  * lean (many-sphere scenes): geometry only.  There a bounce costs n sphere tests and one material
+//    fetch, so the materials stay in global memory (6 dwords per bounce from the 40-byte reference
+//    struct, L2-resident) and the workgroup's LDS footprint drops from 64 to 16 B per sphere: a
+//    1000-sphere scene then runs with as many waves per SIMD as the registers allow instead of two.
 struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
-  float4* mat0;  // {ex, ey, ez, colx}
-  float4* mat1;  // {coly, colz, 0, 0}
-  float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}
+  float4* mat0;  // {ex, ey, ez, colx}          (full layout)
+  float4* mat1;  // {coly, colz, 0, 0}          (full layout)
+  float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
+  const pt_sphere* global;  // the caller's array (lean layout: materials are read from here)
+  bool lean;     // wave-uniform
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n};
+template <bool WITH_PAIR>
+__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean) {
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean};
   const float qnan = __builtin_nanf("");
+  if (lean) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const pt_sphere sp = spheres[i];
+      s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
+    }
+    __syncthreads();
+    return s;
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const pt_sphere sp = spheres[i];
     const float rr = sp.radius * sp.radius;
     s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], rr);
     s.mat0[i] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], sp.color[0]);
     s.mat1[i] = make_float4(sp.color[1], sp.color[2], 0.0f, 0.0f);
-    float* pa = reinterpret_cast<float*>(s.pair + 2 * (i >> 1)) + (i & 1);
-    pa[0] = sp.pos[0];
-    pa[2] = sp.pos[1];
-    pa[4] = sp.pos[2];
-    pa[6] = rr;
-    if ((i == n - 1) && !(i & 1)) {  // odd count: the partner slot is a NaN sphere that can never hit
-      pa[1] = qnan;
-      pa[3] = qnan;
-      pa[5] = qnan;
-      pa[7] = qnan;
+    if constexpr (WITH_PAIR) {
+      float* pa = reinterpret_cast<float*>(s.pair + 2 * (i >> 1)) + (i & 1);
+      pa[0] = sp.pos[0];
+      pa[2] = sp.pos[1];
+      pa[4] = sp.pos[2];
+      pa[6] = rr;
+      if ((i == n - 1) && !(i & 1)) {  // odd count: the partner slot is a NaN sphere that can never hit
+        pa[1] = qnan;
+        pa[3] = qnan;
+        pa[5] = qnan;
+        pa[7] = qnan;
+      }
     }
   }
   __syncthreads();
   return s;
+}
+
+// emission and colour of sphere idx (Scene.h:10-11) from whichever copy the layout keeps
+__device__ __forceinline__ void fetch_material(const SceneLds& sc, int idx, F3& emis, F3& scol) {
+  if (sc.lean) {
+    const pt_sphere* sp = sc.global + idx;
+    emis = mk3(sp->emission[0], sp->emission[1], sp->emission[2]);
+    scol = mk3(sp->color[0], sp->color[1], sp->color[2]);
+  } else {
+    const float4 m0 = sc.mat0[idx];
+    const float4 m1 = sc.mat1[idx];
+    emis = mk3(m0.x, m0.y, m0.z);
+    scol = mk3(m0.w, m1.x, m1.y);
+  }
 }
 
 struct TraceOutput {  // src/pathtrace.cu:24-36

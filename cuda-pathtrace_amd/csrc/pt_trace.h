@@ -7,39 +7,35 @@
 
 namespace pt {
 
-// trace_ray: src/pathtrace.cu:150-201
+// One iteration of the bounce loop (src/pathtrace.cu:155-196) at depth n; false = the ray left the scene
+// (:157-161, the path's colour has been added to L.color and the path is over).
 template <int RNG, int VAR>
-__device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
-                                          Welford (&var)[4], int max_bounces) {
-  F3 color = mk3(0.0f, 0.0f, 0.0f);
-  F3 mask = mk3(1.0f, 1.0f, 1.0f);
-  auto bounce = [&](int n) -> bool {  // one iteration of the loop at :155; false = the ray left the scene
-    float t = 0.0f;
-    int idx = 0;
-    if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
-      L.color = L.color + color;
-      return false;
-    }
-    const float4 g = sc.geom[idx];
-    const float4 m0 = sc.mat0[idx];
-    const float4 m1 = sc.mat1[idx];
-    const F3 emis = mk3(m0.x, m0.y, m0.z);
-    const F3 scol = mk3(m0.w, m1.x, m1.y);
-    F3 normal;
-    float u_az, u_el;
-    if constexpr (VAR >= 6) {
-      // whole geometric step speculatively with the cheap sequences, literal redo if any of them
-      // met an input outside its verified domain (never observed in the Cornell box)
-      rng.bounce(n, u_az, u_el);
-      bool bad = false;
-      BounceGeom bg = bounce_geometry<true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+__device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
+                                            Rng<RNG>& rng, Welford (&var)[4], int n) {
+  float t = 0.0f;
+  int idx = 0;
+  if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
+    L.color = L.color + color;
+    return false;
+  }
+  const float4 g = sc.geom[idx];
+  F3 emis, scol;
+  fetch_material(sc, idx, emis, scol);
+  F3 normal;
+  float u_az, u_el;
+  if constexpr (VAR >= 6) {
+    // whole geometric step speculatively with the cheap sequences, literal redo if any of them
+    // met an input outside its verified domain (never observed in the Cornell box)
+    rng.bounce(n, u_az, u_el);
+    bool bad = false;
+    BounceGeom bg = bounce_geometry<true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
 #ifndef PT_TIMING_ONLY_NO_SHADE_REDO
-      if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+    if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
 #endif
-      normal = bg.normal;
-      o = bg.o;
-      d = bg.d;
-    } else {
+    normal = bg.normal;
+    o = bg.o;
+    d = bg.d;
+  } else {
     F3 pos = o + d * t;                                // :163
     normal = pos - mk3(g.x, g.y, g.z);                 // :164
     if constexpr (VAR >= 4) normal = normalize_fast(normal); else normal = normalize(normal);
@@ -50,33 +46,40 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
       d = normalize_fast(cosine_weighted_fast(normal, u_az, u_el));  // :180
     else
       d = normalize(cosine_weighted(normal, u_az, u_el));
-    }
-    F3 me = mask * emis;
-    if (n == 0)  // :171-172
-      color = color + mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f));
-    else  // :174
-      color = color + me;
-    mask = mask * scol;               // :175
-    if (n == 0) {                     // :187-195
-      L.normal = L.normal + normal;
-      L.albedo = L.albedo + scol;
-      L.depth += t;
-      welford_update(var[1], luminance(normal));
-      welford_update(var[2], luminance(scol));
-      welford_update(var[3], t);
-    }
-    return true;
-  };
+  }
+  F3 me = mask * emis;
+  if (n == 0)  // :171-172
+    color = color + mk3(clampf(me.x, 0.0f, 1.0f), clampf(me.y, 0.0f, 1.0f), clampf(me.z, 0.0f, 1.0f));
+  else  // :174
+    color = color + me;
+  mask = mask * scol;               // :175
+  if (n == 0) {                     // :187-195
+    L.normal = L.normal + normal;
+    L.albedo = L.albedo + scol;
+    L.depth += t;
+    welford_update(var[1], luminance(normal));
+    welford_update(var[2], luminance(scol));
+    welford_update(var[3], t);
+  }
+  return true;
+}
+
+// trace_ray: src/pathtrace.cu:150-201
+template <int RNG, int VAR>
+__device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
+                                          Welford (&var)[4], int max_bounces) {
+  F3 color = mk3(0.0f, 0.0f, 0.0f);
+  F3 mask = mk3(1.0f, 1.0f, 1.0f);
 #if PT_UNROLL_BOUNCES
   if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
 #pragma unroll
     for (int n = 0; n < 5; n++)
-      if (!bounce(n)) return;
+      if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
   } else
 #endif
   {
     for (int n = 0; n < max_bounces; n++)
-      if (!bounce(n)) return;
+      if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
   }
   L.color = L.color + color;                    // :198
   welford_update(var[0], luminance(color));     // :200
@@ -137,11 +140,8 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
       alive[p] = was_alive & hit[p];
       const int ix = alive[p] ? idx[p] : 0;
       const float4 g = sc.geom[ix];
-      const float4 m0 = sc.mat0[ix];
-      const float4 m1 = sc.mat1[ix];
       centre[p] = mk3(g.x, g.y, g.z);
-      emis[p] = mk3(m0.x, m0.y, m0.z);
-      scol[p] = mk3(m0.w, m1.x, m1.y);
+      fetch_material(sc, ix, emis[p], scol[p]);
       u_az[p] = 0.5f;
       u_el[p] = 0.5f;
       if (alive[p]) rng[p].bounce(n, u_az[p], u_el[p]);  // a dead path draws nothing
