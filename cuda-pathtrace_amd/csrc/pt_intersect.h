@@ -15,7 +15,7 @@ __device__ __forceinline__ bool intersect_scene_loop(const SceneLds& sc, int n, 
   float t = 0.0f;
   bool hit = false;
   for (int i = 0; i < n; i++) {
-    const float4 g = sc.geom[i];
+    const float4 g = sc.geom_uniform(i);
     bool h;
     if constexpr (VAR == 0)
       h = intersect_sphere(o, d, rc.a, g, t);
@@ -291,6 +291,9 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
 // screen first runs only the contract's float part and skips the rest of the iteration with one
 // wave-uniform branch when no lane has a real intersection.  Candidates keep full float precision
 // (index tracked separately), the winner alone runs the FP64 path.
+// (Measured and dropped: also rejecting, before the square root, spheres behind the origin or provably
+// farther than the lane's runner-up -- 4ac - 2^-22 bb > 2(1 + 2^-9) T2 |b| -- stayed bit-exact but cost
+// more in the always-executed part than it saved: the conditional part already runs for few iterations.)
 __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                                float& t_hit, int& idx) {
   const float INF = __builtin_inff();
@@ -301,22 +304,22 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
   bool unsure = false;
   struct Head {
     float b, a4c, bb, dacc;
-    uint32_t dd;
   };
-  auto head = [&](const float4 g) {  // the contract's float part: decides det >= 0 exactly
+  auto head = [&](const float4 g) {  // the contract's float part
     const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
     Head h;
     h.b = 2.0f * dot(d, off);
     const float c = dot(off, off) - g.w;
     h.bb = h.b * h.b;
     h.a4c = rc.a4 * c;
-    const float det = h.bb - h.a4c;
+    // One rounding of the exact bb - 4ac: has the sign of the double discriminant of pathtrace.cu:80-81.  The
+    // float determinant of :77 can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|; the tail flags that.
     h.dacc = fmaf(-rc.a4, c, h.bb);
-    h.dd = __float_as_uint(det) | __float_as_uint(h.dacc);
     return h;
   };
   auto tail = [&](const Head& h, int i) {  // estimate + ranking, only when some lane really hits
-    if (__builtin_amdgcn_ballot_w64((int)h.dd >= 0) == 0) return;
+    const bool cand = (int)__float_as_uint(h.dacc) >= 0;
+    if (__builtin_amdgcn_ballot_w64(cand) == 0) return;
     const float s = __builtin_amdgcn_sqrtf(h.dacc);
     const float q = h.b + copysignf(s, h.b);
     const float e = fmaf(h.b, h.b, -h.bb);
@@ -325,29 +328,73 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
     const float TB = -num * __builtin_amdgcn_rcpf(q);
     const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
     const float T = lo > 0.0f ? lo : hi;
-    const bool ok = ((int)(h.dd | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
-    unsure = unsure | (((int)h.dd >= 0) & !(fabsf(num) > fabsf(h.a4c) * 4.7683716e-07f));
+    const bool ok = ((int)(__float_as_uint(h.dacc) | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
+    const float m = fabsf(h.a4c) * 4.7683716e-07f;  // 2^-21 |4ac|
+    unsure = unsure | (cand & !(fminf(fminf(fabsf(num), fabsf(h.dacc)), fabsf(h.a4c)) > m));
     const float Te = ok ? T : INF;
     const bool c1 = Te < T1, c2 = Te < T2;
     T2 = c1 ? T1 : (c2 ? Te : T2);
     i1 = c1 ? i : i1;
     T1 = c1 ? Te : T1;
   };
+  // Four spheres per iteration; one combined test skips all four conditional tails.
   int i = 0;
-  for (; i + 4 <= n; i += 4) {  // four LDS reads and four float parts in flight, then the conditional tails
-    const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1], g2 = sc.geom[i + 2], g3 = sc.geom[i + 3];
+  auto four = [&](const float4 g0, const float4 g1, const float4 g2, const float4 g3) {
     const Head h0 = head(g0), h1 = head(g1), h2 = head(g2), h3 = head(g3);
-    tail(h0, i);
-    tail(h1, i + 1);
-    tail(h2, i + 2);
-    tail(h3, i + 3);
+    const uint32_t all = __float_as_uint(h0.dacc) & __float_as_uint(h1.dacc) & __float_as_uint(h2.dacc) & __float_as_uint(h3.dacc);
+    if (__builtin_amdgcn_ballot_w64((int)all >= 0) != 0) {  // some lane has a non-negative discriminant for one of the four
+      tail(h0, i);
+      tail(h1, i + 1);
+      tail(h2, i + 2);
+      tail(h3, i + 3);
+    }
+  };
+  if (sc.lean) {
+    // Scalar loads, software-pipelined by hand: the requests for iteration k+1 are issued before the
+    // arithmetic of iteration k and waited for after it (the compiler would sink them to their first use
+    // and expose the scalar-cache latency once per iteration), hence inline assembly for both halves.
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const pt_sphere* base = sc.global;
+    auto request = [&](u4& dst, int k) {  // {radius, x, y, z} of sphere min(k, n-1)
+      const uint32_t off = (uint32_t)(k < n ? k : n - 1) * (uint32_t)sizeof(pt_sphere);
+      // "+v"(o.x): the float parts below read o.x, so they are ordered after the request and the
+      // scheduler cannot sink it behind them (it would, to reuse the registers of the previous batch)
+      asm volatile("s_load_dwordx4 %[dst], %[base], %[off]" : [dst] "=s"(dst), "+v"(o.x) : [base] "s"(base), [off] "s"(off));
+    };
+    auto as_geom = [](const u4 v) {
+      const float r = __uint_as_float(v.x);
+      return make_float4(__uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), r * r);
+    };
+    if (n >= 4) {
+      u4 a0, a1, a2, a3;
+      request(a0, 0);
+      request(a1, 1);
+      request(a2, 2);
+      request(a3, 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
+      for (; i + 4 <= n; i += 4) {
+        u4 b0, b1, b2, b3;
+        request(b0, i + 4);
+        request(b1, i + 5);
+        request(b2, i + 6);
+        request(b3, i + 7);
+        four(as_geom(a0), as_geom(a1), as_geom(a2), as_geom(a3));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
+        a0 = b0;
+        a1 = b1;
+        a2 = b2;
+        a3 = b3;
+      }
+    }
+  } else {
+    for (; i + 4 <= n; i += 4) four(sc.geom[i], sc.geom[i + 1], sc.geom[i + 2], sc.geom[i + 3]);
   }
-  for (; i < n; i++) tail(head(sc.geom[i]), i);
+  for (; i < n; i++) tail(head(sc.geom_uniform(i)), i);
   const bool has = T1 < INF;
   bool ambiguous = unsure | (has & ((T2 <= T1 * 1.0000038f) | (T1 >= Tlim * 0.99998f)));
   float t;
   bool bad = false;
-  const bool real = intersect_sphere_nb(o, d, rc, sc.geom[i1], t, bad);
+  const bool real = intersect_sphere_nb(o, d, rc, sc.geom_lane(i1), t, bad);
   const bool good = real & (t > 0.0f) & (t < 1000000.0f);
   ambiguous = ambiguous | (has & (bad | !good));
   t_hit = t;
@@ -364,7 +411,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
-    if (n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+    if (!sc.lean && n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
     if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }
@@ -389,7 +436,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     hit[p] = false;
   }
   if (n <= 0) return;
-  if (n > PT_SCREEN_MAX_SPHERES) {
+  if (sc.lean || n > PT_SCREEN_MAX_SPHERES) {
 #pragma unroll
     for (int p = 0; p < P; p++) hit[p] = intersect_scene_screened_large(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
     return;

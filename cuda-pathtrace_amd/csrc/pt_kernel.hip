@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
-                         !LEAN;  // the lean layout has no transpose slice (its frames take long enough not to care)
+  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u);
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
 #pragma unroll
@@ -390,14 +389,14 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 static inline bool lds_lean(int n, int variant) { return n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10); }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
-  if (lds_lean(n, variant)) return (size_t)n;
+  if (lds_lean(n, variant)) return 0;  // the lean builds read the caller's array directly
   return (size_t)n * 3 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);
 }
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
-  return lds_lean(n, variant) ? 0 : (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
+  return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
 static inline size_t scene_lds_bytes(int n, int variant) { return scene_lds_f4(n, variant) * sizeof(float4) + tail_lds_bytes(n, variant); }
 
@@ -438,10 +437,9 @@ const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres) {
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(n_spheres, variant); }
 
 int pt_kernel_max_spheres(int variant) {
-  // variants with a lean build are bounded by 16 B per sphere, the others by their full image
+  // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 10) return (int)(PT_LDS_BUDGET_BYTES / sizeof(float4));
-  if (variant == 8) return (int)((PT_LDS_BUDGET_BYTES - tail) / sizeof(float4));
+  if (variant == 6 || variant == 8 || variant == 10) return INT32_MAX;
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (4 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
 }

@@ -13,19 +13,43 @@ namespace pt {
 // LDS image of the scene: geometry and material split so the intersect loop touches
 // 16 B per sphere with a wave-uniform address (LDS broadcast read), and the shading step
 // gathers 32 B by the per-lane hit index.
-// Two layouts (chosen by the launcher, PixelKernelArgs::lds_layout):
-//  * full (scenes up to PT_SCREEN_MAX_SPHERES): geometry + materials (+ the paired image variant 3 reads);
-//  * lean (many-sphere scenes): geometry only.  There a bounce costs n sphere tests and one material
-//    fetch, so the materials stay in global memory (6 dwords per bounce from the 40-byte reference
-//    struct, L2-resident) and the workgroup's LDS footprint drops from 64 to 16 B per sphere: a
-//    1000-sphere scene then runs with as many waves per SIMD as the registers allow instead of two.
+// Two layouts (chosen by the launcher; a compile-time property of the kernel build):
+//  * LDS image (scenes up to PT_SCREEN_MAX_SPHERES): geometry + materials (+ the paired image variant 3 reads);
+//  * lean (many-sphere scenes): NO LDS image.  A wave64 LDS read of one 16-byte sphere is a 1 KiB
+//    broadcast, and with 1000 tests per bounce that broadcast traffic -- not the arithmetic -- bounded the
+//    loop (25.6 ns per wave and sphere at 16 waves per CU).  The sphere index is wave-uniform, so the
+//    lean build fetches {radius, centre} with SCALAR loads straight from the caller's 40-byte structs
+//    (constant address space -> s_load_dwordx4 through the scalar cache; the operands then sit in SGPRs
+//    and cost no VGPR, no LDS cycle and no staging pass), and gathers the winner's geometry and material
+//    per lane from global memory once per bounce.  No LDS footprint means the register file alone sets
+//    the occupancy, and there is no scene-size limit.
 struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
-  float4* mat0;  // {ex, ey, ez, colx}          (full layout)
-  float4* mat1;  // {coly, colz, 0, 0}          (full layout)
+  float4* mat0;  // {ex, ey, ez, colx}
+  float4* mat1;  // {coly, colz, 0, 0}
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
-  const pt_sphere* global;  // the caller's array (lean layout: materials are read from here)
-  bool lean;     // wave-uniform
+  const pt_sphere* global;  // the caller's array (lean build)
+  bool lean;     // compile-time constant after inlining
+
+  // geometry of sphere i, i wave-uniform
+  __device__ __forceinline__ float4 geom_uniform(int i) const {
+    if (lean) {
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      typedef const __attribute__((address_space(4))) f4u* cptr;
+      typedef const __attribute__((address_space(4))) char* cbytes;
+      const f4u v = *(cptr)((cbytes)global + (size_t)i * sizeof(pt_sphere));  // {radius, x, y, z}: Scene.h:8-9
+      return make_float4(v.y, v.z, v.w, v.x * v.x);
+    }
+    return geom[i];
+  }
+  // geometry of sphere i, i per lane
+  __device__ __forceinline__ float4 geom_lane(int i) const {
+    if (lean) {
+      const pt_sphere* sp = global + i;
+      return make_float4(sp->pos[0], sp->pos[1], sp->pos[2], sp->radius * sp->radius);
+    }
+    return geom[i];
+  }
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -34,14 +58,7 @@ template <bool WITH_PAIR>
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean) {
   SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean};
   const float qnan = __builtin_nanf("");
-  if (lean) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const pt_sphere sp = spheres[i];
-      s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
-    }
-    __syncthreads();
-    return s;
-  }
+  if (lean) return s;  // nothing is staged
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const pt_sphere sp = spheres[i];
     const float rr = sp.radius * sp.radius;

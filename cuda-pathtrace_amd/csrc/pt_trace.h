@@ -18,7 +18,7 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
     L.color = L.color + color;
     return false;
   }
-  const float4 g = sc.geom[idx];
+  const float4 g = sc.geom_lane(idx);
   F3 emis, scol;
   fetch_material(sc, idx, emis, scol);
   F3 normal;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
       res[p].escaped = res[p].escaped | (was_alive & !hit[p]);  // :157-161
       alive[p] = was_alive & hit[p];
       const int ix = alive[p] ? idx[p] : 0;
-      const float4 g = sc.geom[ix];
+      const float4 g = sc.geom_lane(ix);
       centre[p] = mk3(g.x, g.y, g.z);
       fetch_material(sc, ix, emis[p], scol[p]);
       u_az[p] = 0.5f;
