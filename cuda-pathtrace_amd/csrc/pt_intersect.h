@@ -293,7 +293,10 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
 // (index tracked separately), the winner alone runs the FP64 path.
 // (Measured and dropped: also rejecting, before the square root, spheres behind the origin or provably
 // farther than the lane's runner-up -- 4ac - 2^-22 bb > 2(1 + 2^-9) T2 |b| -- stayed bit-exact but cost
-// more in the always-executed part than it saved: the conditional part already runs for few iterations.)
+// more in the always-executed part than it saved: the conditional part already runs for few iterations.
+// Also measured and dropped: two spheres per packed-FP32 instruction in the float part (43 instead of 80
+// VALU instructions per four spheres, operands straight from SGPR pairs) -- 12 % SLOWER; with the plain
+// form the loop already runs at the measured issue peak, 24.5 ns per wave and sphere for 21.6 issue units.)
 __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                                float& t_hit, int& idx) {
   const float INF = __builtin_inff();
