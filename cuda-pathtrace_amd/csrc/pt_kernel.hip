@@ -439,7 +439,7 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(
 int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 8 || variant == 10) return INT32_MAX;
+  if (variant == 6 || variant == 8 || variant == 10) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (4 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
 }
