@@ -16,7 +16,11 @@
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES
-#define PT_SCREEN_MAX_SPHERES 64  // variants >= 5 use the key-based screen up to this size, the many-sphere screen above
+// Variants >= 5 use the key-based screen (every sphere fully evaluated, branch-free) up to this size and the
+// many-sphere loop (float part, wave-uniform skip, scalar loads) above.  Measured crossover on random scenes
+// with walls, 1024^2 x 16 spp (tools/threshold_sweep.py): 10 spheres 1.32 vs 1.36 ms, 12: 1.39 vs 1.32,
+// 24: 2.02 vs 1.63, 64: 4.40 vs 2.81.  The key-based screen needs n <= 64 (index bits in the key).
+#define PT_SCREEN_MAX_SPHERES 10
 #endif
 #ifndef PT_UNROLL_BOUNCES
 #define PT_UNROLL_BOUNCES 1  // also emit a fully unrolled path for the reference's MAX_BOUNCES = 5 (+6 %)

@@ -141,7 +141,7 @@ typedef struct pt_kernel_info {
   int32_t num_vgprs;    /* from hipFuncGetAttributes */
   int32_t num_sgprs;
   int32_t scratch_bytes;
-  int32_t max_spheres;  /* LDS staging limit for this variant (2^26 where scenes above 64 spheres are not staged) */
+  int32_t max_spheres;  /* LDS staging limit for this variant (2^26 where larger scenes are not staged) */
   int32_t variant;      /* the variant the next launch will use (resolves the automatic choice) */
 } pt_kernel_info;
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info);

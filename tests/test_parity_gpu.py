@@ -356,7 +356,7 @@ def test_fuzz_random_scenes_all_variants(pt, oracle, gpu, seed):
     surfaces), random cameras, both generators: every variant must equal the oracle bit for bit.
     Duplicated spheres force the first-index tie-break and the 'ambiguous -> literal loop' path."""
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(1, 40)) if seed % 4 else int(rng.integers(65, 120))  # also the > 64-sphere path
+    n = int(rng.integers(1, 40)) if seed % 4 else int(rng.integers(65, 120))  # also scenes above the key-based screen's 64-sphere limit
     scene = _random_scene(rng, n)
     size = 48
     eye = tuple(rng.uniform([20, 20, 100], [80, 60, 300]))
