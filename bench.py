@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (default: the library default)")
     ap.add_argument("--spp", type=int, default=SPP, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-rng", action="store_true", help="skip the extra philox measurement")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~10 s)")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame to this .npy (tests)")
     args = ap.parse_args()
@@ -128,56 +129,67 @@ def main():
     # two frame/tile buffer sets: the gather of step k (RCCL stream) overlaps the render of step k+1
     fgs = [tiling.FrameGather(WIDTH, HEIGHT, device) for _ in range(2 if world > 1 else 1)]
     fg = fgs[0]
-    pending = [[] for _ in fgs]
     rb, re_ = fg.rows
-    renderer = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant,
-                           persist_rng=True)
     d_scene = torch.from_numpy(spheres.view("u1").reshape(-1).copy()).to(device)
     stream = torch.cuda.current_stream()
-
     step_no = [0]
 
-    def step(ev=None):
-        slot = step_no[0] % len(fgs)
-        step_no[0] += 1
-        f = fgs[slot]
-        f.wait_all(pending[slot])  # the gather that last used this buffer set must have finished
-        if ev is not None:
-            ev[0].record(stream)
-        renderer.enqueue(f.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
-        if ev is not None:
-            ev[1].record(stream)
-        pending[slot] = f.gather()
+    def measure(mode):
+        """W untimed + K timed frames with generator `mode`: (renderer, whole-job seconds, kernel seconds), max over ranks."""
+        rend = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=True)
+        pending = [[] for _ in fgs]
 
-    def sync():
-        for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
-            f.wait_all(pending[slot])
-            pending[slot] = []
+        def step(ev=None):
+            slot = step_no[0] % len(fgs)
+            step_no[0] += 1
+            f = fgs[slot]
+            f.wait_all(pending[slot])  # the gather that last used this buffer set must have finished
+            if ev is not None:
+                ev[0].record(stream)
+            rend.enqueue(f.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
+            if ev is not None:
+                ev[1].record(stream)
+            pending[slot] = f.gather()
+
+        def sync():
+            for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
+                f.wait_all(pending[slot])
+                pending[slot] = []
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        sync()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(events[k])
+        sync()
+        dt = time.perf_counter() - t0
+        k_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+        tmax = torch.tensor([dt, k_ms / 1e3], dtype=torch.float64, device=device)
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return rend, tmax[0].item(), tmax[1].item()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    sync()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-
-    tmax = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, kernel_s = tmax[0].item(), tmax[1].item()
-
+    renderer, elapsed, kernel_s = measure(rng_mode)
+    main_last_slot = (step_no[0] - 1) % len(fgs)
     if rank == 0 and args.dump:
         import numpy as np
 
-        last = fgs[(step_no[0] - 1) % len(fgs)]
-        np.save(args.dump, last.frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+        np.save(args.dump, fgs[main_last_slot].frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+    # the same measurement with the counter-based generator (north star: "a counter-based RNG in registers
+    # replacing curand"); reported beside the headline, which stays on the reference's XORWOW stream
+    alt = None
+    if args.rng == "xorwow" and not args.no_alt_rng:
+        r2, e2, k2 = measure(pt.RNG_PHILOX)
+        alt = {"rng": "philox4x32-10 (counter-based, no state traffic)", "value": round(WIDTH * HEIGHT * spp * args.steps / e2 / 1e6, 2),
+               "unit": "Msamples/s", "ms_per_step": round(e2 / args.steps * 1e3, 3), "kernel_ms": round(k2 * 1e3, 3),
+               "kernel_variant": r2.kernel_info(len(spheres))["variant"]}
+        r2.destroy()
+
     if rank == 0:
         total_samples = WIDTH * HEIGHT * spp * args.steps
         ms_per_step = elapsed / args.steps * 1e3
@@ -236,6 +248,7 @@ def main():
                         "f32+f64), so the HBM fraction is <<1% by construction",
             },
             "valu_roofline": valu,
+            "counter_based_rng": alt,
             "kernel_info": ki,
         }
         if world == 1 and not args.no_cpu_baseline:
