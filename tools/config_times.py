@@ -42,6 +42,32 @@ run("cfg4_1000spheres_open_1024x1024x256spp", 1024, 256, pt.scene_random(1000, s
 run("cfg5_512x512x4spp_8bounces_per_frame", 512, 4, cornell, reps=20, max_bounces=8)
 run("cfg5_philox", 512, 4, cornell, reps=20, max_bounces=8, rng_mode=pt.RNG_PHILOX)
 run("cfg1_256x256x4spp", 256, 4, cornell, reps=10)
+
+
+def frame_stream(name, size, spp, frames=200, **kw):
+    """cfg5's shape: frames enqueued back to back on one stream, one sync at the end -- is the loop launch-bound?"""
+    import time
+    basis = pt.camera_basis(width=size, height=size)
+    r = pt.Renderer(size, size, spp, variant=variant, **kw)
+    d_scene, n = pt.upload_scene(cornell)
+    d_out = pt.DeviceBuffer(size * size * 14 * 4)
+    kernel_ms = min(r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(5))
+    pt.check(pt.lib.pt_device_synchronize())
+    t = time.perf_counter()
+    for _ in range(frames):
+        r.enqueue(d_out.ptr, d_scene.ptr, n, basis)
+    t_enq = time.perf_counter() - t
+    pt.check(pt.lib.pt_device_synchronize())
+    wall = time.perf_counter() - t
+    r.destroy()
+    res = {"frames": frames, "kernel_ms": round(kernel_ms, 4), "wall_ms_per_frame": round(wall / frames * 1e3, 4),
+           "host_enqueue_us_per_frame": round(t_enq / frames * 1e6, 2)}
+    out[name] = res
+    print(name, res, flush=True)
+
+
+frame_stream("cfg5_stream_200_frames_512x512x4spp_8bounces", 512, 4, max_bounces=8)
+frame_stream("cfg5_stream_200_frames_philox", 512, 4, max_bounces=8, rng_mode=pt.RNG_PHILOX)
 # PCIe-inclusive single-frame mode (main.cu:187-188): D2H copy of the 58.7 MB buffer into pageable host memory
 import time
 buf = pt.DeviceBuffer(1024 * 1024 * 56)
