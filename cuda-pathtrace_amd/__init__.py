@@ -99,6 +99,7 @@ ABI = {
     "pt_debug_unary_map": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "pt_debug_unary_compare": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_debug_grid_header": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
 FN_INV_SQRT_LITERAL, FN_INV_SQRT_FAST, FN_SQRT_LITERAL, FN_SQRT_FAST, FN_SIN, FN_COS, FN_UNIFORM = range(7)
@@ -226,6 +227,18 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def grid_header(spheres):
+    """Diagnostics: the header of kernel variant 11's uniform grid for a scene (pt_debug_grid_header)."""
+    d_scene, n = upload_scene(spheres)
+    raw = (ctypes.c_uint32 * 16)()
+    check(lib.pt_debug_grid_header(d_scene.ptr, n, raw))
+    u = np.frombuffer(raw, dtype=np.uint32).copy()
+    f = u.view(np.float32)
+    return {"valid": int(u[0]), "dims": (int(u[1]), int(u[2]), int(u[3])), "origin": (float(f[4]), float(f[5]), float(f[6])),
+            "cell_size": float(f[7]), "slack": float(f[9]), "centre": (float(f[10]), float(f[11]), float(f[12])),
+            "far2": float(f[13]), "n_big": int(u[14]), "n_items": int(u[15])}
 
 
 def upload_scene(spheres):

@@ -48,6 +48,7 @@ struct pt_renderer {
   uint32_t* h_fail;        // pinned host copy, valid once ev_fail has completed
   hipEvent_t ev_fail;
   bool fail_pending;
+  uint32_t* d_accel;       // variant 11's grid tables (rebuilt on the device before every frame)
 };
 
 // Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD (measured:
@@ -194,6 +195,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->h_fail = nullptr;
   r->ev_fail = nullptr;
   r->fail_pending = false;
+  r->d_accel = nullptr;
   hipError_t e = hipGetDevice(&r->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -207,6 +209,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (e == hipSuccess) e = hipMemset(r->d_fail, 0, sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_fail, sizeof(uint32_t), hipHostMallocDefault);
   if (e == hipSuccess) { *r->h_fail = 0; e = hipEventCreateWithFlags(&r->ev_fail, hipEventDisableTiming); }
+  if (e == hipSuccess) e = hipMalloc((void**)&r->d_accel, pt_kernel_accel_bytes());
   if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
   if (e == hipSuccess && o.rng_mode == PT_RNG_XORWOW && o.persist_rng && r->tile_pixels)
@@ -228,6 +231,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
 int pt_renderer_destroy(pt_renderer* r) {
   if (!r) return PT_OK;
   if (r->d_state) (void)hipFree(r->d_state);  // Renderer.h:50
+  if (r->d_accel) (void)hipFree(r->d_accel);
   if (r->d_fail) (void)hipFree(r->d_fail);
   if (r->h_fail) (void)hipHostFree(r->h_fail);
   if (r->ev_fail) (void)hipEventDestroy(r->ev_fail);
@@ -248,6 +252,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
     return pt_fail(PT_ELIMIT, "render: %d spheres exceed the LDS staging limit of %d", n_spheres,
                    pt_kernel_max_spheres(variant));
   a->fail_count = r->d_fail;
+  a->accel = r->d_accel;
   a->scene_lds_f4 = 0;
   r->launch_variant = variant;
   a->out = d_out;
@@ -366,6 +371,18 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;
   info->max_spheres = pt_kernel_max_spheres(variant);
+  return PT_OK;
+}
+
+// diagnostics: build variant 11's grid for a scene and return its 16-word header
+int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]) {
+  if (!d_spheres || !header_out || n_spheres < 1) return pt_fail(PT_EINVAL, "pt_debug_grid_header: bad arguments");
+  uint32_t* d = nullptr;
+  PT_HIP(hipMalloc((void**)&d, pt_kernel_accel_bytes()));
+  hipError_t e = pt_launch_build_grid(d_spheres, n_spheres, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(header_out, d, 64, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PT_HIP(e);
   return PT_OK;
 }
 

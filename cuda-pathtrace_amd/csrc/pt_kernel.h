@@ -12,7 +12,8 @@
 #endif
 // Kernel variants (all bit-identical): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
 // FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
-// lane, 8 four lanes per pixel, 9 two lanes per pixel, 10 per-lane path regeneration (open scenes).
+// lane, 8 four lanes per pixel, 9 two lanes per pixel, 10 per-lane path regeneration (open scenes), 11 = 10 + a
+// conservative uniform grid over the small spheres (pt_grid.h).
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES
@@ -56,6 +57,7 @@ struct PixelKernelArgs {
   uint32_t frame;
   uint32_t scene_lds_f4;       // float4 slots of the LDS scene image (filled in by the launcher)
   uint32_t* fail_count;        // variant 8: number of pixels whose speculation failed (may be nullptr)
+  const uint32_t* accel;       // variant 11: the grid built by build_grid_kernel for this frame's scene
   uint64_t seed;
 };
 
@@ -64,5 +66,7 @@ const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres);
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, hipStream_t stream);
+size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);

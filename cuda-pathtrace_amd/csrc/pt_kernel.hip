@@ -17,7 +17,13 @@ namespace pt {
 template <int RNG, int VAR, bool LEAN = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
-  const SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  constexpr bool kRegen = (VAR == 10 || VAR == 11);
+  GridLds grid;
+  if constexpr (VAR == 11) {  // the frame's grid, built by build_grid_kernel just before this launch
+    grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene);
+    sc.grid = &grid;
+  }
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;  // pixel index inside the tile
   const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
@@ -67,7 +73,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   };
 
   int i = active ? 0 : a.spp;  // inactive lanes trace nothing
-  if constexpr (VAR == 10) {
+  if constexpr (kRegen) {
     // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
     // per lane): the sample loop and the bounce loop are flattened into one per-lane state machine, so a
     // lane whose path left the scene starts its next sample at once instead of idling until the longest
@@ -87,7 +93,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
       }
       bool escaped = false;
       if (n < a.max_bounces) {
-        escaped = !bounce_once<RNG, 6>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
+        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
         n++;
       }
       if (escaped | (n >= a.max_bounces)) {
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
       }
     }
   }
-  if constexpr (VAR >= 7 && VAR != 10) {
+  if constexpr (VAR >= 7 && !kRegen) {
     const int draws = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;  // consumed by a path that never escapes
     for (; i + 2 <= a.spp; i += 2) {
       Rng<RNG> g[2] = {rng, rng};
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
       }
     }
   }
-  if constexpr (VAR != 10) {
+  if constexpr (!kRegen) {
     for (; i < a.spp; i++) {  // :219
       rng.begin_sample((uint32_t)i);
       F3 dir;
@@ -144,7 +150,8 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u);
+  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
+                         VAR != 11;  // variant 11's LDS holds the grid until the last wave is done: plain stores there
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
 #pragma unroll
@@ -386,7 +393,9 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 // ---- launchers (host) ---------------------------------------------------------------------
 // LDS layout of a launch (pt_scene_lds.h): many-sphere scenes keep only the geometry in LDS
 // (variants 6, 8 and 10 -- the ones the automatic policy uses -- are also built for that layout)
-static inline bool lds_lean(int n, int variant) { return n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10); }
+static inline bool lds_lean(int n, int variant) {
+  return variant == 11 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
+}
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
   if (lds_lean(n, variant)) return 0;  // the lean builds read the caller's array directly
@@ -395,6 +404,7 @@ static inline size_t scene_lds_f4(int n, int variant) {
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
+  if (variant == 11) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n) : 64;  // geometry + grid tables instead of the epilogue slice
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
   return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
@@ -409,6 +419,7 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean) {
       case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, true>;
       case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
       case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
+      case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
       default: return nullptr;
     }
   }
@@ -428,7 +439,20 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean) {
   }
 }
 
-int pt_kernel_num_variants(void) { return 11; }
+int pt_kernel_num_variants(void) { return 12; }
+
+size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
+
+#ifdef PT_GRID_DEBUG
+extern "C" int pt_debug_grid_counters(unsigned long long out[8], int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_grid_dbg), 64);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pt::g_grid_dbg), z, 64);
+  }
+  return e == hipSuccess ? 0 : -2;
+}
+#endif
 
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres) {
   return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant));
@@ -439,9 +463,14 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(
 int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 8 || variant == 10) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
+  if (variant == 6 || variant == 8 || variant == 10 || variant == 11) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (4 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
+}
+
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, hipStream_t stream) {
+  hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel);
+  return hipGetLastError();
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
@@ -453,6 +482,11 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   if (lds > PT_LDS_BUDGET_BYTES) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  if (variant == 11) {  // this frame's grid (the scene may have changed since the last one)
+    if (!a.accel) return hipErrorInvalidValue;
+    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), stream);
     if (e != hipSuccess) return e;
   }
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);

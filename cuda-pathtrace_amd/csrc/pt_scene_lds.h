@@ -23,6 +23,8 @@ namespace pt {
 //    and cost no VGPR, no LDS cycle and no staging pass), and gathers the winner's geometry and material
 //    per lane from global memory once per bounce.  No LDS footprint means the register file alone sets
 //    the occupancy, and there is no scene-size limit.
+struct GridLds;  // pt_grid.h
+
 struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
   float4* mat0;  // {ex, ey, ez, colx}
@@ -30,6 +32,7 @@ struct SceneLds {
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
+  const GridLds* grid;  // variant 11 only
 
   // geometry of sphere i, i wave-uniform
   __device__ __forceinline__ float4 geom_uniform(int i) const {
@@ -56,7 +59,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool WITH_PAIR>
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean};
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean, nullptr};
   const float qnan = __builtin_nanf("");
   if (lean) return s;  // nothing is staged
   for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -1,7 +1,7 @@
 // pt_trace.h -- one path (src/pathtrace.cu:150-201): accumulating form (trace_ray) and the
 // result-returning lockstep form (trace_paths + accumulate_path) used by variants 7 and 8.
 #pragma once
-#include "pt_intersect.h"
+#include "pt_grid.h"
 
 #pragma clang fp contract(off)
 
@@ -14,7 +14,12 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
                                             Rng<RNG>& rng, Welford (&var)[4], int n) {
   float t = 0.0f;
   int idx = 0;
-  if (!intersect_scene<VAR>(sc, nsph, o, d, t, idx)) {  // :157-161
+  bool hit;
+  if constexpr (VAR == 11)
+    hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
+  else
+    hit = intersect_scene<VAR>(sc, nsph, o, d, t, idx);
+  if (!hit) {  // :157-161
     L.color = L.color + color;
     return false;
   }
