@@ -66,6 +66,7 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   // 1000-sphere scene: 35.5 -> 25.7 ms at 16 spp; closed scenes: equal to variant 6).
   // A small closed tile still gains from four lanes per pixel (1/8 tile, 1000 spheres + walls: 17.9 vs 23.3 ms);
   // the speculation feedback above sends an open scene back to variant 10.
+  if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 11;  // fewer tests: the uniform grid
   if (n_spheres > PT_SCREEN_MAX_SPHERES)
     return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
   // philox is counter-based: no skip-ahead, no speculation, and the four-lane kernel needs fewer

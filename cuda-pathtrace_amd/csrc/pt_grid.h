@@ -20,6 +20,13 @@
 //    tables go to a list every lane tests; if the tables overflow the header says invalid and the kernel
 //    uses the brute-force loop.
 // Evidence: bit-identical to variant 10 and to the CPU oracle on the fuzz and many-sphere tests.
+//
+// Divergence: a ray tests 12-19 registered spheres on average but the slowest lane of a wave needs ~5x that,
+// so the walk runs at ~20 % lane utilisation and the gain over the brute-force loop is 2.2x, not 10x.
+// Measured and dropped: running the walk as a state machine inside the regeneration loop (lanes whose walk is
+// over wait, are shaded and re-launched in batches of 16-56 while the others keep walking) -- bit-exact, but
+// 10-15 % slower at every batch size: the per-trip control and the repeated big shading block cost more
+// than the idle lanes did.  Grid resolution (1, 2, 4, 8 cells per sphere) changes the time by < 10 %.
 #pragma once
 #include "pt_intersect.h"
 
@@ -36,7 +43,7 @@ namespace pt {
 constexpr int kGridMaxCells = PT_GRID_MAX_CELLS;
 constexpr int kGridMaxItems = 8192;
 constexpr int kGridMaxBig = 64;
-constexpr int kGridMaxSpheres = 2048;  // geometry of all spheres is staged (16 B each)
+constexpr int kGridMaxSpheres = PT_GRID_MAX_SPHERES;  // geometry of all spheres is staged (16 B each)
 constexpr int kGridBuildThreads = 1024;
 
 struct GridHeader {  // 64 bytes, written by build_grid_kernel
@@ -320,12 +327,6 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
 }
 
 // ---- traversal ---------------------------------------------------------------------------------------
-#ifdef PT_GRID_DEBUG
-__device__ unsigned long long g_grid_dbg[8];  // rays, iterations, tests, steps, ambiguous lanes, unsure lanes, not admitted, wave iterations
-#define PT_GRID_COUNT(k, v) atomicAdd(&g_grid_dbg[k], (unsigned long long)(v))
-#else
-#define PT_GRID_COUNT(k, v)
-#endif
 struct Near2 {
   float T1, T2;  // two smallest estimates of 2a*t
   int i1;
@@ -415,20 +416,11 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
   c = active ? c : 0;
   uint32_t k0 = G.cell_start[c], k1 = G.cell_start[c + 1];
   if (!active) k1 = k0;
-  PT_GRID_COUNT(0, 1);
   while (active) {
-    PT_GRID_COUNT(1, 1);
-#ifdef PT_GRID_DEBUG
-    {
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-      if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) PT_GRID_COUNT(7, 1);
-    }
-#endif
     if (k0 < k1) {
       const int i = (int)G.items[k0];
       k0++;
       near2_test(s, G.geom[i], i, true, o, d, rc, Tlim_hi);
-      PT_GRID_COUNT(2, 1);
     }
     if (k0 >= k1) {  // cell finished: leave through the nearest wall
       const float t_exit = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
@@ -460,18 +452,6 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
   const bool real = intersect_sphere_nb(o, d, rc, G.geom[s.i1], t, bad);
   const bool good = real & (t > 0.0f) & (t < 1000000.0f);
   ambiguous = ambiguous | (has & (bad | !good));
-  PT_GRID_COUNT(4, ambiguous ? 1 : 0);
-#ifdef PT_GRID_DEBUG
-  {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-    const unsigned long long am = __builtin_amdgcn_ballot_w64(ambiguous);
-    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) {
-      PT_GRID_COUNT(3, 1);                  // wave-level calls
-      if (am) PT_GRID_COUNT(6, 1);          // wave-level calls that run the literal loop
-    }
-  }
-#endif
-  PT_GRID_COUNT(5, s.unsure ? 1 : 0);
   t_hit = t;
   idx = s.i1;
   bool hit = has & good;

@@ -39,6 +39,10 @@
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the
 // 9-sphere scene with many).
 #define PT_LDS_BUDGET_BYTES (96 * 1024)
+// Variant 11 (uniform grid, pt_grid.h) stages the geometry of every sphere (16 B each) beside its tables; it pays from
+// about 200 spheres (150 spheres + walls: 3.2 vs 3.0-3.3 ms, 300: 5.9 vs 4.3, 1000: 18.1 vs 7.6; tools/grid_check.py).
+#define PT_GRID_MAX_SPHERES 2048
+#define PT_GRID_MIN_SPHERES 192
 
 // Everything pixel_kernel needs travels as kernel arguments (SGPRs): the camera is 60 B, so
 // the reference's two per-frame cudaMemcpy H2D (Renderer.h:59-60) disappear.

@@ -443,16 +443,6 @@ int pt_kernel_num_variants(void) { return 12; }
 
 size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 
-#ifdef PT_GRID_DEBUG
-extern "C" int pt_debug_grid_counters(unsigned long long out[8], int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_grid_dbg), 64);
-  if (e == hipSuccess && reset) {
-    unsigned long long z[8] = {0};
-    e = hipMemcpyToSymbol(HIP_SYMBOL(pt::g_grid_dbg), z, 64);
-  }
-  return e == hipSuccess ? 0 : -2;
-}
-#endif
 
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres) {
   return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant));

@@ -191,6 +191,44 @@ def test_edge_cases(pt, oracle, gpu):
 
 
 @pytest.mark.parametrize("rng", [0, 1])
+def test_uniform_grid_variant(pt, oracle, gpu, rng):
+    """Variant 11 changes which spheres a lane tests (conservative uniform grid, rebuilt on the device every
+    frame), never the result: against the oracle on closed/open scenes, a far-away camera (rays not admitted
+    to the grid), radii spanning two decades (grid refused: too many spheres that cannot be registered) and a
+    scene changed in place between two frames of one renderer."""
+    size = 40
+    cams = [((50.0, 52.0, 295.6), -90.0, 0.0), ((50.0, 40.0, 85.0), -60.0, 10.0), ((-900.0, 700.0, 2500.0), -70.0, -15.0)]
+    scenes = {"walls": pt.scene_random(400, seed=21, with_walls=True), "open": pt.scene_random(400, seed=22, with_walls=False)}
+    wide = pt.scene_random(400, seed=23, with_walls=True)
+    wide["radius"][7:] = np.exp(np.random.default_rng(5).uniform(np.log(0.02), np.log(8.0), size=len(wide) - 7)).astype(np.float32)
+    scenes["radii 0.02-8"] = wide
+    for name, scene in scenes.items():
+        for eye, yaw, pitch in cams:
+            basis = pt.camera_basis(eye, yaw, pitch, size, size)
+            ref = oracle.render(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng)
+            for v in (11, None):
+                img, _ = pt.render_frame(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=v)
+                assert_bit_exact(img, ref, f"grid {name} eye={eye} variant={v}")
+    assert pt.grid_header(scenes["walls"])["valid"] == 1 and pt.grid_header(wide)["valid"] == 0
+    r = pt.Renderer(size, size, 3, rng_mode=rng)
+    assert r.kernel_info(400)["variant"] == 11
+    # the grid belongs to the frame, not to the renderer: move the spheres between two frames
+    basis = pt.camera_basis(width=size, height=size)
+    a, b = scenes["walls"], scenes["walls"].copy()
+    b["pos"][7:, 0] = 100.0 - b["pos"][7:, 0]
+    d_scene, n = pt.upload_scene(a)
+    d_out = pt.DeviceBuffer(size * size * 56)
+    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    st = r.get_rng_state() if rng == 0 else None
+    d_scene.upload(b)
+    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    got = d_out.download(np.float32, (size, size, 14))
+    r.destroy()
+    ref = oracle.render(size, size, 3, spheres=b, basis=basis, rng_mode=rng, rng_state=st, frame=1)
+    assert_bit_exact(got, ref, "scene changed in place between frames")
+
+
+@pytest.mark.parametrize("rng", [0, 1])
 def test_many_sphere_lean_lds_layout(pt, oracle, gpu, rng):
     """Scenes above PT_SCREEN_MAX_SPHERES are not staged into LDS: the sphere loop reads the caller's array
     with scalar loads, the winner's geometry and material are gathered per lane.  3000 spheres exceed what
