@@ -26,7 +26,8 @@
 // Measured and dropped: running the walk as a state machine inside the regeneration loop (lanes whose walk is
 // over wait, are shaded and re-launched in batches of 16-56 while the others keep walking) -- bit-exact, but
 // 10-15 % slower at every batch size: the per-trip control and the repeated big shading block cost more
-// than the idle lanes did.  Grid resolution (1, 2, 4, 8 cells per sphere) changes the time by < 10 %.
+// than the idle lanes did.  Grid resolution (1, 2, 4, 8 cells per sphere) changes the time by < 10 %; a filter
+// against re-testing the last two spheres (a sphere spans ~2.9 cells) gained 1 %.
 #pragma once
 #include "pt_intersect.h"
 
