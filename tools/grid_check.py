@@ -36,9 +36,36 @@ cases.append(("clustered_gaussian", sc))
 sc = pt.scene_random(600, seed=7, with_walls=False)
 sc["pos"][:, 1] = 20.0  # coplanar
 cases.append(("coplanar_open", sc))
-cams = [((50.0, 52.0, 295.6), -90.0, 0.0), ((50.0, 40.0, 85.0), -60.0, 10.0), ((-150.0, 200.0, 500.0), -55.0, -20.0)]
+# adversarial geometry: lattice aligned with the cell walls, axis-parallel rays, touching / nested / duplicated spheres
+g = np.arange(0, 12)
+lat = np.array([(4.0 + 8.0 * x, 4.0 + 8.0 * y, 4.0 + 8.0 * z) for x in g[:10] for y in g[:8] for z in g[:12]], dtype=np.float32)
+sc = pt.scene_random(len(lat), seed=8, with_walls=False)
+sc["pos"] = lat
+sc["radius"] = 4.0  # neighbours touch exactly
+cases.append(("lattice_touching", sc))
+sc = sc.copy()
+sc["radius"] = 2.0
+cases.append(("lattice_r2", sc))
+sc = pt.scene_random(900, seed=9, with_walls=True)
+sc["pos"][300:600] = sc["pos"][7:307]          # nested: same centres, different radii
+sc["radius"][300:600] = sc["radius"][7:307] * 0.5
+sc[600:893] = sc[7:300]                        # exact duplicates (ties -> first index must win)
+cases.append(("nested_and_duplicates", sc))
+for scale in (0.01, 100.0):
+    sc = pt.scene_random(700, seed=10, with_walls=False)
+    sc["pos"] *= scale
+    sc["radius"] *= scale
+    cases.append((f"scaled_x{scale}", sc))
+sc = pt.scene_random(500, seed=11, with_walls=True)
+sc["radius"][7:20] = [0.0, -1.0, np.nan, 1e-30, 1e30, np.inf, 0.0, 0.0, 1e-3, 1e-3, 1e-3, 40.0, 60.0]
+cases.append(("degenerate_radii", sc))
+scaled_cams = {"scaled_x0.01": 0.01, "scaled_x100.0": 100.0}
+cams = [((50.0, 52.0, 295.6), -90.0, 0.0), ((50.0, 40.0, 85.0), -60.0, 10.0), ((-150.0, 200.0, 500.0), -55.0, -20.0),
+        ((44.0, 36.0, -200.0), 90.0, 0.0)]  # the last one looks straight down a lattice row (axis-parallel centre rays)
 for name, scene in cases:
     for ci, (eye, yaw, pitch) in enumerate(cams):
+        if name in scaled_cams:
+            eye = tuple(c * scaled_cams[name] for c in eye)
         basis = pt.camera_basis(eye, yaw, pitch, size, size)
         mode = ci % 2
         a, ms10 = frame(scene, basis, eye, 10, mode)
