@@ -27,7 +27,8 @@
 // over wait, are shaded and re-launched in batches of 16-56 while the others keep walking) -- bit-exact, but
 // 10-15 % slower at every batch size: the per-trip control and the repeated big shading block cost more
 // than the idle lanes did.  Grid resolution (1, 2, 4, 8 cells per sphere) changes the time by < 10 %; a filter
-// against re-testing the last two spheres (a sphere spans ~2.9 cells) gained 1 %.
+// against re-testing the last two spheres (a sphere spans ~2.9 cells) gained 1 %; resolving ambiguous lanes with the
+// reference's FP64 test on a second walk instead of the literal loop over all spheres changed nothing measurable.
 #pragma once
 #include "pt_intersect.h"
 
