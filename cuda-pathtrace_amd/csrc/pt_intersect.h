@@ -414,7 +414,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
-    if (!sc.lean && n <= PT_SCREEN_MAX_SPHERES) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+    if (!sc.lean && (sc.small_only || n <= PT_SCREEN_MAX_SPHERES)) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
     if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }
@@ -439,7 +439,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     hit[p] = false;
   }
   if (n <= 0) return;
-  if (sc.lean || n > PT_SCREEN_MAX_SPHERES) {
+  if (sc.lean || (!sc.small_only && n > PT_SCREEN_MAX_SPHERES)) {
 #pragma unroll
     for (int p = 0; p < P; p++) hit[p] = intersect_scene_screened_large(sc, n, o[p], d[p], rc[p], t_hit[p], idx[p]);
     return;

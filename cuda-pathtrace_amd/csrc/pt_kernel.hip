@@ -18,6 +18,9 @@ template <int RNG, int VAR, bool LEAN = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  // variants with a lean build run their LDS build only on scenes up to PT_SCREEN_MAX_SPHERES (launcher): the
+  // many-sphere path is not even compiled into it, which keeps the hot loop's code small
+  sc.small_only = !LEAN && (VAR == 6 || VAR == 8 || VAR == 10);
   constexpr bool kRegen = (VAR == 10 || VAR == 11);
   GridLds grid;
   if constexpr (VAR == 11) {  // the frame's grid, built by build_grid_kernel just before this launch
@@ -207,7 +210,8 @@ template <int RNG, int kSplit, bool LEAN = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
-  const SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  sc.small_only = !LEAN && kSplit == 4;  // variant 8 has a lean build for larger scenes, variant 9 has not
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
   const int gbase = lane & ~(kSplit - 1);

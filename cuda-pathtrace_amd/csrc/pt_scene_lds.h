@@ -32,6 +32,7 @@ struct SceneLds {
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
+  bool small_only;  // compile-time constant: this kernel build is only launched for scenes up to PT_SCREEN_MAX_SPHERES
   const GridLds* grid;  // variant 11 only
 
   // geometry of sphere i, i wave-uniform
@@ -59,7 +60,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool WITH_PAIR>
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean, nullptr};
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean, false, nullptr};
   const float qnan = __builtin_nanf("");
   if (lean) return s;  // nothing is staged
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
