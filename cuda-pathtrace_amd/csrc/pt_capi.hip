@@ -361,7 +361,7 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
   hipFuncAttributes fa;
   const int variant = effective_variant(r, n_spheres);
-  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres)));
+  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces)));
   info->block_threads = PT_BLOCK_THREADS;
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);

@@ -14,6 +14,9 @@ __device__ __forceinline__ bool intersect_scene_loop(const SceneLds& sc, int n, 
   float tNearest = 1000000.0f;
   float t = 0.0f;
   bool hit = false;
+  // never unrolled: in the fast variants this loop is the cold fallback, inlined once per bounce, and its size
+  // would otherwise push the hot path out of the instruction cache when n is a compile-time constant
+#pragma clang loop unroll(disable)
   for (int i = 0; i < n; i++) {
     const float4 g = sc.geom_uniform(i);
     bool h;

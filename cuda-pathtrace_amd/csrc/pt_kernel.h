@@ -66,7 +66,7 @@ struct PixelKernelArgs {
 };
 
 int pt_kernel_num_variants(void);
-const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres);
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces);
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);

@@ -14,8 +14,14 @@ namespace pt {
 // pixel_kernel: src/pathtrace.cu:203-257
 // LEAN selects the geometry-only LDS layout of many-sphere scenes (pt_scene_lds.h) at compile time, so the
 // 9-sphere kernels carry no trace of it.
-template <int RNG, int VAR, bool LEAN = false>
+// REF builds the kernel for the reference's own configuration -- 9 spheres (Scene.h:23), MAX_BOUNCES 5 (pathtrace.cu:7) -- as
+// compile-time constants: no generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
+template <int RNG, int VAR, bool LEAN = false, bool REF = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+  if constexpr (REF) {
+    a.n_spheres = 9;
+    a.max_bounces = 5;
+  }
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
   // variants with a lean build run their LDS build only on scenes up to PT_SCREEN_MAX_SPHERES (launcher): the
@@ -206,8 +212,12 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
 // skip-ahead, for tiles that are only moderately too small (about 4 one-lane waves per SIMD).
 constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
 
-template <int RNG, int kSplit, bool LEAN = false>
+template <int RNG, int kSplit, bool LEAN = false, bool REF = false>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
+  if constexpr (REF) {
+    a.n_spheres = 9;
+    a.max_bounces = 5;
+  }
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN);
@@ -416,8 +426,17 @@ static inline size_t scene_lds_bytes(int n, int variant) { return scene_lds_f4(n
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
-static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean) {
+static inline bool ref_config(int n, int max_bounces, int variant) {
+  return n == 9 && max_bounces == 5 && (variant == 6 || variant == 8);
+}
+
+static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool ref) {
   const bool philox = rng_mode == PT_RNG_PHILOX;
+  if (ref && !lean) {
+    if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, true>;
+    if (variant == 8)
+      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, true>;
+  }
   if (lean) {
     switch (variant) {
       case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, true>;
@@ -448,8 +467,8 @@ int pt_kernel_num_variants(void) { return 12; }
 size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 
 
-const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres) {
-  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant));
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces) {
+  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant));
 }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(n_spheres, variant); }
@@ -468,7 +487,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
-  pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant));
+  pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant), ref_config(a.n_spheres, a.max_bounces, variant));
   if (!fn) return hipErrorInvalidValue;
   PixelKernelArgs b = a;
   b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, variant);
