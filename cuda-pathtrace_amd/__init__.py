@@ -50,7 +50,11 @@ class RendererOpts(ctypes.Structure):
         ("row_end", ctypes.c_int32),
         ("persist_rng", ctypes.c_int32),
         ("variant", ctypes.c_int32),
+        ("layout", ctypes.c_int32),
     ]
+
+
+LAYOUT_INTERLEAVED, LAYOUT_PLANAR = 0, 1
 
 
 class KernelInfo(ctypes.Structure):
@@ -250,12 +254,13 @@ class Renderer:
     """ctypes view of pt_renderer (the reference's class Renderer, include/Renderer.h)."""
 
     def __init__(self, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 row_begin=0, row_end=0, persist_rng=True, variant=None):
+                 row_begin=0, row_end=0, persist_rng=True, variant=None, layout=LAYOUT_INTERLEAVED):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
         o.row_begin, o.row_end = row_begin, row_end
         o.persist_rng = 1 if persist_rng else 0
+        o.layout = layout
         if variant is not None:
             o.variant = variant
         self.variant = o.variant

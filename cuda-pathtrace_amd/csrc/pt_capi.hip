@@ -142,6 +142,7 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
   o->rng_mode = PT_RNG_XORWOW;
   o->persist_rng = 1;
   o->variant = PT_VARIANT_AUTO;
+  o->layout = PT_LAYOUT_INTERLEAVED;
 }
 
 static int setup_random(pt_renderer* r) {
@@ -169,6 +170,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.max_bounces < 0 || o.max_bounces > 64) return pt_fail(PT_EINVAL, "pt_renderer_create: max_bounces %d", o.max_bounces);
   if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
     return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
+  if (o.layout != PT_LAYOUT_INTERLEAVED && o.layout != PT_LAYOUT_PLANAR) return pt_fail(PT_EINVAL, "pt_renderer_create: layout %d", o.layout);
   if (o.variant != PT_VARIANT_AUTO && (o.variant < 0 || o.variant >= pt_kernel_num_variants()))
     return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d (have %d)", o.variant, pt_kernel_num_variants());
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
@@ -255,6 +257,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->fail_count = r->d_fail;
   a->accel = r->d_accel;
   a->scene_lds_f4 = 0;
+  a->planar = r->opts.layout == PT_LAYOUT_PLANAR ? 1u : 0u;
   r->launch_variant = variant;
   a->out = d_out;
   a->spheres = d_spheres;

@@ -60,6 +60,7 @@ struct PixelKernelArgs {
   int32_t max_bounces;
   uint32_t frame;
   uint32_t scene_lds_f4;       // float4 slots of the LDS scene image (filled in by the launcher)
+  uint32_t planar;             // 1 = channel-first output [14][tile rows][width] instead of [row][col][14]
   uint32_t* fail_count;        // variant 8: number of pixels whose speculation failed (may be nullptr)
   const uint32_t* accel;       // variant 11: the grid built by build_grid_kernel for this frame's scene
   uint64_t seed;

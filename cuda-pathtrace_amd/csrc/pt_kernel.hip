@@ -158,6 +158,13 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
   // The 64 pixels of a wave are 64 consecutive columns, so their 64 x 14 floats are ONE contiguous
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
+  if (!REF && a.planar) {  // channel-first: consecutive lanes are consecutive columns of one plane, stores coalesce as they are
+    // (the reference-configuration builds are interleaved-only: the launcher sends planar frames to the generic build)
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 14; c++) a.out[(size_t)c * a.tile_pixels + tp] = px[c];
+    }
+  } else {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
                          VAR != 11;  // variant 11's LDS holds the grid until the last wave is done: plain stores there
@@ -177,6 +184,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
     float* o = a.out + (size_t)tp * 14;
 #pragma unroll
     for (int c = 0; c < 14; c++) o[c] = px[c];
+  }
   }
 
   if constexpr (RNG == PT_RNG_XORWOW) {
@@ -362,18 +370,21 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
 
   if (active) {  // :234-254, each lane stores its feature
     const float fs = (float)a.spp;
-    float* o = a.out + (size_t)tp * 14;
+    // channel c of this pixel: interleaved [row][col][14] or channel-first [14][tile pixels]
+    const bool planar = !REF && a.planar;
+    float* o = planar ? a.out + tp : a.out + (size_t)tp * 14;
+    const size_t cs = planar ? (size_t)a.tile_pixels : 1;
 #pragma unroll
     for (int q = 0; q < kOwn; q++) {
       const int f = s * kOwn + q;
       if (f < 3) {
-        o[3 * f + 0] = sum0[q] / fs;
-        o[3 * f + 1] = sum1[q] / fs;
-        o[3 * f + 2] = sum2[q] / fs;
+        o[(3 * f + 0) * cs] = sum0[q] / fs;
+        o[(3 * f + 1) * cs] = sum1[q] / fs;
+        o[(3 * f + 2) * cs] = sum2[q] / fs;
       } else {
-        o[9] = sum0[q] / fs;
+        o[9 * cs] = sum0[q] / fs;
       }
-      o[10 + f] = welford_variance(w[q]);
+      o[(10 + f) * cs] = welford_variance(w[q]);
     }
     if constexpr (RNG == PT_RNG_XORWOW) {
       if (a.rng_state && s == 0) {  // :256
@@ -426,8 +437,8 @@ static inline size_t scene_lds_bytes(int n, int variant) { return scene_lds_f4(n
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
-static inline bool ref_config(int n, int max_bounces, int variant) {
-  return n == 9 && max_bounces == 5 && (variant == 6 || variant == 8);
+static inline bool ref_config(int n, int max_bounces, int variant, bool planar) {
+  return n == 9 && max_bounces == 5 && !planar && (variant == 6 || variant == 8);
 }
 
 static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool ref) {
@@ -468,7 +479,7 @@ size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 
 
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces) {
-  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant));
+  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant, false));
 }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(n_spheres, variant); }
@@ -487,7 +498,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
-  pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant), ref_config(a.n_spheres, a.max_bounces, variant));
+  pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant), ref_config(a.n_spheres, a.max_bounces, variant, a.planar != 0u));
   if (!fn) return hipErrorInvalidValue;
   PixelKernelArgs b = a;
   b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, variant);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 enum {
   PT_OK = 0,
@@ -58,6 +58,8 @@ enum {
   PT_RNG_PHILOX = 1  /* counter-based Philox4x32-10 keyed on (seed, frame); stateless           */
 };
 
+enum { PT_LAYOUT_INTERLEAVED = 0, PT_LAYOUT_PLANAR = 1 };
+
 /* Options that the reference hard-codes or keeps in Renderer; zero-initialise then call
  * pt_renderer_opts_default(). */
 typedef struct pt_renderer_opts {
@@ -69,8 +71,11 @@ typedef struct pt_renderer_opts {
   int32_t persist_rng;  /* xorwow only: keep per-pixel generator state across Render()     */
                         /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
   int32_t variant;      /* kernel variant, all produce identical bits: -1 (default) = automatic    */
-                        /*   (6, or 8 = four lanes per pixel when the tile is too small to fill    */
-                        /*   the GPU), 0 = literal transcription, 1..8 see DESIGN.md               */
+                        /*   (by scene size, tile size and generator), 0 = literal transcription,  */
+                        /*   1..11 see DESIGN.md section 4                                         */
+  int32_t layout;       /* PT_LAYOUT_INTERLEAVED (default): the reference's [row][col][14] buffer  */
+                        /*   (pathtrace.cu:240-254); PT_LAYOUT_PLANAR: [14][rows][width] of this   */
+                        /*   renderer's tile -- same values, channel-first like a torch NCHW tensor */
 } pt_renderer_opts;
 
 typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */

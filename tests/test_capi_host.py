@@ -28,12 +28,12 @@ def test_library_exports_every_declared_symbol(pt):
 
 
 def test_abi_version_and_struct_layout(pt):
-    assert pt.lib.pt_abi_version() == 1
+    assert pt.lib.pt_abi_version() == 2
     assert pt.SPHERE_DTYPE.itemsize == 40          # include/Scene.h:7-14
-    assert ctypes.sizeof(pt.RendererOpts) == 32
+    assert ctypes.sizeof(pt.RendererOpts) == 40
     o = pt.RendererOpts()
     pt.lib.pt_renderer_opts_default(ctypes.byref(o))
-    assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant) == (5, 0, 0, 1, -1)
+    assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant, o.layout) == (5, 0, 0, 1, -1, pt.LAYOUT_INTERLEAVED)
 
 
 def test_cornell_scene_matches_oracle_table(pt, oracle):

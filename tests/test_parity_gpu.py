@@ -191,6 +191,26 @@ def test_edge_cases(pt, oracle, gpu):
 
 
 @pytest.mark.parametrize("rng", [0, 1])
+def test_planar_layout_is_the_transposed_frame(pt, oracle, gpu, rng):
+    """PT_LAYOUT_PLANAR writes [14][rows][width] (channel-first, coalesced without the LDS transpose); the values
+    are the reference's, so the planes must equal the oracle's interleaved frame transposed -- every kernel
+    family (one lane per pixel, four lanes per pixel, regeneration, grid), full frame and a row tile."""
+    size, spp = 72, 5
+    basis = pt.camera_basis(width=size, height=size)
+    for scene, variants in ((pt.scene_cornell(), (0, 6, 8, 9, None)), (pt.scene_random(300, seed=4), (6, 8, 10, 11, None))):
+        ref = oracle.render(size, size, spp, spheres=scene, basis=basis, rng_mode=rng)
+        for v in variants:
+            img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, rng_mode=rng, variant=v, layout=pt.LAYOUT_PLANAR)
+            planes = img.reshape(14, size, size)
+            assert_bit_exact(np.ascontiguousarray(planes.transpose(1, 2, 0)), ref, f"planar variant={v}")
+    tile, _ = pt.render_frame(size, size, spp, basis=basis, rng_mode=rng, row_begin=17, row_end=50, layout=pt.LAYOUT_PLANAR)
+    full = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
+    assert_bit_exact(np.ascontiguousarray(tile.reshape(14, 33, size).transpose(1, 2, 0)), full[17:50], "planar tile")
+    with pytest.raises(pt.PtError):
+        pt.Renderer(8, 8, 1, layout=7)
+
+
+@pytest.mark.parametrize("rng", [0, 1])
 def test_uniform_grid_variant(pt, oracle, gpu, rng):
     """Variant 11 changes which spheres a lane tests (conservative uniform grid, rebuilt on the device every
     frame), never the result: against the oracle on closed/open scenes, a far-away camera (rays not admitted
