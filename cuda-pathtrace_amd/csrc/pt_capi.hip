@@ -49,7 +49,25 @@ struct pt_renderer {
   hipEvent_t ev_fail;
   bool fail_pending;
   uint32_t* d_accel;       // variant 11's grid tables (rebuilt on the device before every frame)
+  // The renderer owns single-instance device scratch (generator state, d_accel, d_fail): launches of one
+  // renderer must execute in submission order even when the caller alternates streams.
+  hipEvent_t ev_last;      // recorded after every launch on the stream it went to
+  hipStream_t last_stream;
+  bool have_last;
 };
+
+// Order this launch after the renderer's previous one if that went to a different stream.
+static int order_after_last(pt_renderer* r, hipStream_t stream) {
+  if (r->have_last && r->last_stream != stream) PT_HIP(hipStreamWaitEvent(stream, r->ev_last, 0));
+  return PT_OK;
+}
+
+static int mark_last(pt_renderer* r, hipStream_t stream) {
+  PT_HIP(hipEventRecord(r->ev_last, stream));
+  r->last_stream = stream;
+  r->have_last = true;
+  return PT_OK;
+}
 
 // Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD (measured:
 // 4 waves/SIMD: 21.3 vs 22.3 ms, 2 waves/SIMD: 11.3 vs 12.7 ms, 8 and more: variant 6 wins).
@@ -199,6 +217,9 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->ev_fail = nullptr;
   r->fail_pending = false;
   r->d_accel = nullptr;
+  r->ev_last = nullptr;
+  r->last_stream = nullptr;
+  r->have_last = false;
   hipError_t e = hipGetDevice(&r->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -213,6 +234,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_fail, sizeof(uint32_t), hipHostMallocDefault);
   if (e == hipSuccess) { *r->h_fail = 0; e = hipEventCreateWithFlags(&r->ev_fail, hipEventDisableTiming); }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_accel, pt_kernel_accel_bytes());
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_last, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
   if (e == hipSuccess && o.rng_mode == PT_RNG_XORWOW && o.persist_rng && r->tile_pixels)
@@ -238,6 +260,7 @@ int pt_renderer_destroy(pt_renderer* r) {
   if (r->d_fail) (void)hipFree(r->d_fail);
   if (r->h_fail) (void)hipHostFree(r->h_fail);
   if (r->ev_fail) (void)hipEventDestroy(r->ev_fail);
+  if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   if (r->ev_start) (void)hipEventDestroy(r->ev_start);
   if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
   delete r;
@@ -299,11 +322,15 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
   int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
   if (rc != PT_OK) return rc;
   if (r->tile_pixels == 0) return PT_OK;
+  rc = order_after_last(r, (hipStream_t)hip_stream);
+  if (rc != PT_OK) return rc;
   bool watching = false;
   rc = watch_begin(r, (hipStream_t)hip_stream, &watching);
   if (rc != PT_OK) return rc;
   PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->launch_variant, (hipStream_t)hip_stream));
   rc = watch_end(r, (hipStream_t)hip_stream, watching);
+  if (rc != PT_OK) return rc;
+  rc = mark_last(r, (hipStream_t)hip_stream);
   if (rc != PT_OK) return rc;
   r->frame++;
   return PT_OK;
@@ -316,6 +343,8 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   if (rc != PT_OK) return rc;
   if (ms_out) *ms_out = 0.0f;
   if (r->tile_pixels == 0) return PT_OK;
+  rc = order_after_last(r, nullptr);
+  if (rc != PT_OK) return rc;
   bool watching = false;
   rc = watch_begin(r, nullptr, &watching);
   if (rc != PT_OK) return rc;
@@ -325,6 +354,7 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   rc = watch_end(r, nullptr, watching);
   if (rc != PT_OK) return rc;
   PT_HIP(hipEventSynchronize(r->ev_stop));       // Renderer.h:72
+  r->have_last = false;  // the launch has completed: nothing left to order against
   r->frame++;
   float ms = 0.0f;
   PT_HIP(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
@@ -364,7 +394,7 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
   hipFuncAttributes fa;
   const int variant = effective_variant(r, n_spheres);
-  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces)));
+  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR)));
   info->block_threads = PT_BLOCK_THREADS;
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);

@@ -463,6 +463,7 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
 
 // variant 11's nearest-hit search: the grid when the build produced one, the brute-force loop otherwise
 __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+  if (n <= 0) return false;
   const RayConst rc = make_ray_const(d);
   const GridLds& G = *sc.grid;
   if (G.valid) {

@@ -302,6 +302,7 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
 // form the loop already runs at the measured issue peak, 24.5 ns per wave and sphere for 21.6 issue units.)
 __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                                float& t_hit, int& idx) {
+  if (n <= 0) return false;  // empty scene: nothing to test and no sphere 0 to evaluate below (the array may be NULL)
   const float INF = __builtin_inff();
   const float Tlim = 1000000.0f * (2.0f * rc.a);
   const float Tlim_hi = Tlim * 1.0000153f;

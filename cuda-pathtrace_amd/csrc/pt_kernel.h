@@ -67,7 +67,7 @@ struct PixelKernelArgs {
 };
 
 int pt_kernel_num_variants(void);
-const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces);
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);

@@ -478,8 +478,8 @@ int pt_kernel_num_variants(void) { return 12; }
 size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 
 
-const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces) {
-  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant, false));
+const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar) {
+  return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant, planar));
 }
 
 size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(n_spheres, variant); }

@@ -127,7 +127,11 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
 /* Same launch without host synchronisation, on the caller's HIP stream (hipStream_t passed
  * as void*; NULL = the default stream).  Used by bench.py and the multi-GPU driver so the
  * kernel overlaps with the caller's copies/collectives and can be timed with the caller's
- * events.  The camera (60 B) travels as kernel arguments: no H2D copy, no allocation. */
+ * events.  The camera (60 B) travels as kernel arguments: no H2D copy, no allocation.
+ * One renderer's launches always execute in submission order: the renderer owns per-frame device
+ * scratch (generator state, grid tables), so a launch on a different stream than the previous one
+ * first waits (hipStreamWaitEvent) for that previous launch.  Frames that should overlap need
+ * separate renderers. */
 int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
                         const float basis[12], const float eye[3], void* hip_stream);
 

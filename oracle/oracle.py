@@ -36,6 +36,19 @@ class Params(ctypes.Structure):
     ]
 
 
+def usable_cores():
+    """Threads the oracle may really use: the scheduler affinity mask capped by the cgroup CPU quota
+    (a GPU box exposes 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or (
@@ -113,7 +126,7 @@ def render(width, height, spp, spheres=None, basis=None, eye=(50.0, 52.0, 295.6)
     if basis is None:
         basis = camera_basis(eye, w=width, h=height)
     if threads is None:
-        threads = os.cpu_count() or 1
+        threads = usable_cores()
     spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
     basis = np.ascontiguousarray(basis, dtype=np.float32).reshape(12)
     eye = np.ascontiguousarray(eye, dtype=np.float32).reshape(3)

@@ -94,11 +94,8 @@ def test_compute_fails_loudly_without_gpu(pt):
         pt.DeviceBuffer(1024)
 
 
-def test_header_is_strict_c99_and_example_fails_loudly_without_gpu(pt, tmp_path):
-    """INTEGRATION.md's raw C binding compiled with gcc -std=c99 -pedantic against include/ptcore.h."""
+def _build_abi_example(tmp_path):
     import subprocess
-
-    from conftest import ROOT
 
     exe = str(tmp_path / "abi_example")
     libdir = os.path.join(ROOT, "cuda-pathtrace_amd")
@@ -106,7 +103,14 @@ def test_header_is_strict_c99_and_example_fails_loudly_without_gpu(pt, tmp_path)
                           os.path.join(ROOT, "tests", "cpp", "abi_example.c"), "-L", libdir, "-lptcore",
                           "-Wl,-rpath," + libdir], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
-    run = subprocess.run([exe], capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_strict_c99_and_example_fails_loudly_without_gpu(pt, tmp_path):
+    """INTEGRATION.md's raw C binding compiled with gcc -std=c99 -pedantic against include/ptcore.h."""
+    import subprocess
+
+    run = subprocess.run([_build_abi_example(tmp_path)], capture_output=True, text=True)
     try:
         have_gpu = pt.device_count() > 0
     except pt.PtError:
@@ -115,3 +119,18 @@ def test_header_is_strict_c99_and_example_fails_loudly_without_gpu(pt, tmp_path)
         assert run.returncode == 0 and run.stdout.startswith("ok ")
     else:
         assert run.returncode == 3 and "device" in run.stderr.lower()
+
+
+@pytest.mark.gpu
+def test_abi_example_success_path_on_the_gpu(pt, oracle, gpu, tmp_path):
+    """The same plain-C program on a real device: renders 64 x 64 x 4 spp through the raw C ABI, prints the
+    kernel time, and -- with a file name -- dumps the frame, which must equal the oracle bit for bit."""
+    import subprocess
+
+    dump = str(tmp_path / "frame.f32")
+    run = subprocess.run([_build_abi_example(tmp_path), dump], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert run.stdout.startswith("ok ") and "abi %d" % pt.lib.pt_abi_version() in run.stdout
+    img = np.fromfile(dump, dtype=np.float32).reshape(64, 64, 14)
+    ref = oracle.render(64, 64, 4, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=64, height=64))
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
