@@ -2,14 +2,18 @@
 """bench.py -- headline benchmark of the path-trace megakernel on MI355X.
 
 Metric (BASELINE.json): Msamples/s (+ ms/frame) on the 9-sphere Cornell box, 1024 x 1024,
-1024 spp, fixed seed.  A "step" is one frame: one pass of the hot path over the whole image.
-At N GPUs the image is row-tiled (rank g renders rows row_range(H, N, g)) and gathered to
-rank 0 over RCCL at frame end; the timed region includes that gather.  Total work is fixed as
-N grows -> "scaling": "strong".
+1024 spp, fixed seed (--config cfg2, the default).  --config cfg3 is BASELINE.json configs[2]:
+4096 x 4096 x 64 spp, the 8-GPU row-tiled configuration.  A "step" is one frame: one pass of the
+hot path over the whole image.  At N GPUs the image is row-tiled (rank g renders rows
+row_range(H, N, g)) and gathered to rank 0 over RCCL at frame end; the timed region includes
+that gather.  Total work is fixed as N grows -> "scaling": "strong".
 
   python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --gpus N [--config cfg3]        # spawns its N ranks itself (one process per GPU, RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N --steps K --warmup W      # the driver's form: same ranks
+  python bench.py --gpus N --engine native       # ONE process: libptcore's pt_mgpu_* (a host thread per
+                                                 # device, RCCL inside the library), no torch.distributed
 
 Rank 0 prints ONE JSON line.  Inputs (scene 360 B, camera 60 B) are resident / kernel
 arguments before the timed region starts; output stays in HBM (the reference's interactive
@@ -18,16 +22,23 @@ mode never copies it to the host either, src/main.cu:146-177).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH = HEIGHT = 1024
-SPP = 1024
+CONFIGS = {  # BASELINE.json `configs`
+    "cfg2": {"width": 1024, "height": 1024, "spp": 1024, "name": "BASELINE.json configs[1]"},
+    "cfg3": {"width": 4096, "height": 4096, "spp": 64, "name": "BASELINE.json configs[2]"},
+}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL = 56   # 14 x f32 written per pixel per frame
+# VALU issue peak from MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
+# ("v_fma_f32 (wave64): 2 cyc"), 256 CUs x 4 SIMDs, 2.4 GHz -> 1024 x 2.4e9 / 2 wave-instructions per second
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # = 1228.8 G wave-instr/s
 
 
 def usable_cores():
@@ -43,30 +54,100 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(oracle, spheres, basis, rows):
+def cpu_baseline(oracle, cfg, spheres, basis, rows):
     """Oracle (CPU restatement, kind 'port') on the usable host cores over a bounded sample of the
-    same workload: a band of `rows` image rows at the full 1024 columns x 1024 spp."""
+    same workload: a band of `rows` full-width image rows at the configuration's spp.  Two builds of
+    the same source: the parity build (-O2 -ffp-contract=off: the arithmetic the GPU
+    is checked against; this is `value`) and -O3 -march=native (`native_build`, timing only)."""
+    w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
     cores = usable_cores()
-    if rows <= 0:  # size the sample for about 10 s of wall time from a short probe, capped at the full frame
-        probe_rows = 8
+    if rows <= 0:  # size the sample for about 8 s of wall time per build from a short probe, capped at the full frame
+        probe_rows = max(1, 8 * 1024 * 1024 // (w * spp))
         t = time.perf_counter()
-        oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=HEIGHT // 2, row_end=HEIGHT // 2 + probe_rows,
-                      threads=cores)
-        rate = probe_rows * WIDTH * SPP / (time.perf_counter() - t)
-        rows = int(max(8, min(HEIGHT, 10.0 * rate / (WIDTH * SPP))))
-    r0 = HEIGHT // 2 - rows // 2
-    t = time.perf_counter()
-    oracle.render(WIDTH, HEIGHT, SPP, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores)
-    dt = time.perf_counter() - t
-    samples = rows * WIDTH * SPP
-    return {
+        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=h // 2, row_end=h // 2 + probe_rows, threads=cores)
+        rate = probe_rows * w * spp / (time.perf_counter() - t)
+        rows = int(max(probe_rows, min(h, 8.0 * rate / (w * spp))))
+    r0 = h // 2 - rows // 2
+    samples = rows * w * spp
+
+    def timed(native):
+        t = time.perf_counter()
+        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores, native=native)
+        return time.perf_counter() - t
+
+    dt = timed(False)
+    out = {
         "value": round(samples / dt / 1e6, 3),
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"rows {r0}..{r0 + rows - 1} of the 1024x1024 frame at 1024 spp ({samples / 1e6:.1f} Msamples, {dt:.1f} s wall), "
-                  "gcc -O2 -ffp-contract=off, pthreads over rows",
+        "sample": f"rows {r0}..{r0 + rows - 1} of the {w}x{h} frame at {spp} spp ({samples / 1e6:.1f} Msamples, {dt:.1f} s wall), "
+                  "gcc -O2 -ffp-contract=off (the parity build), pthreads over rows",
     }
+    try:
+        oracle.native_lib()  # compiled here, on the machine it runs on
+        dn = timed(True)
+        out["native_build"] = {"value": round(samples / dn / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+                               "flags": "gcc -O3 -march=native (default FP contraction; timing only, not the contract's arithmetic)",
+                               "seconds": round(dn, 1)}
+    except Exception as e:  # a missing compiler must not lose the headline
+        out["native_build"] = {"error": str(e)[:200]}
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes
+    (this parent has not touched the GPU and never does), one per GPU, rendezvous on 127.0.0.1."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:  # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def profile_records(pt, cfg_key, rng, ki):
+    """Counters measured with rocprofv3 (profiles/*.json) for exactly this build and kernel, or (None, None, why)."""
+    key = f"{cfg_key}_{rng}_v{ki['variant']}"
+    why = None
+    recs = []
+    for name in ("hbm_traffic.json", "valu_roofline.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        rec = None
+        if os.path.exists(path):
+            try:
+                rec = json.load(open(path)).get(key)
+            except Exception:
+                rec = None
+        if rec is None:
+            why = why or f"no profile for {key}"
+        elif rec.get("fingerprint") != pt.build_fingerprint() or rec.get("num_vgprs") != ki["num_vgprs"]:
+            why = f"profile {key} was measured on build {rec.get('fingerprint')} ({rec.get('num_vgprs')} VGPRs), this is {pt.build_fingerprint()} ({ki['num_vgprs']} VGPRs)"
+            rec = None
+        recs.append(rec)
+    return recs[0], recs[1], why
 
 
 def main():
@@ -74,14 +155,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--engine", choices=["dist", "native"], default="dist",
+                    help="dist: one process per GPU, torch.distributed over RCCL; native: one process, libptcore pt_mgpu_*")
     ap.add_argument("--rng", choices=["xorwow", "philox"], default="xorwow")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (default: the library default)")
-    ap.add_argument("--spp", type=int, default=SPP, help="override spp (invalidates the headline config)")
+    ap.add_argument("--spp", type=int, default=None, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-rng", action="store_true", help="skip the extra philox measurement")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~10 s)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~8 s per build)")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame to this .npy (tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and args.engine == "dist" and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))  # before anything here touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -91,18 +178,23 @@ def main():
     pt = ge.load_package()
     from cuda_pathtrace_amd import tiling
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    cfg = dict(CONFIGS[args.config])
+    if args.spp is not None:
+        cfg["spp"] = args.spp
+    WIDTH, HEIGHT, spp = cfg["width"], cfg["height"], cfg["spp"]
+    headline_config = args.spp is None
+
+    native = args.engine == "native"
+    world = 1 if native else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if native else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if native else int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus if native else world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # PT_BENCH_SHARED_GPU=1 + PT_BENCH_BACKEND=gloo: functional test of the multi-rank path with all
     # ranks on GPU 0 (tests/test_bench_multirank_gpu.py); the driver's runs use one GPU per rank + RCCL
-    dev_index = 0 if os.environ.get("PT_BENCH_SHARED_GPU") == "1" else local_rank
+    shared = os.environ.get("PT_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared else local_rank
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     pt.set_device(dev_index)
@@ -120,108 +212,136 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    spp = args.spp
     rng_mode = pt.RNG_PHILOX if args.rng == "philox" else pt.RNG_XORWOW
     spheres = pt.scene_cornell()
     basis = pt.camera_basis(width=WIDTH, height=HEIGHT)
     eye = pt.DEFAULT_EYE
-
-    # two frame/tile buffer sets: the gather of step k (RCCL stream) overlaps the render of step k+1
-    fgs = [tiling.FrameGather(WIDTH, HEIGHT, device) for _ in range(2 if world > 1 else 1)]
-    fg = fgs[0]
-    rb, re_ = fg.rows
     d_scene = torch.from_numpy(spheres.view("u1").reshape(-1).copy()).to(device)
     stream = torch.cuda.current_stream()
-    step_no = [0]
+    total_samples = WIDTH * HEIGHT * spp * args.steps
 
-    def measure(mode):
-        """W untimed + K timed frames with generator `mode`: (renderer, whole-job seconds, kernel seconds), max over ranks."""
-        rend = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=True)
-        pending = [[] for _ in fgs]
+    if native:
+        # ---- one process, libptcore's own multi-GPU entry (pt_mgpu_*) -------------------------------------
+        devs = [0] * n_gpus if shared else list(range(n_gpus))
+        frame = torch.empty(HEIGHT * WIDTH * 14, dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
 
-        def step(ev=None):
-            slot = step_no[0] % len(fgs)
-            step_no[0] += 1
-            f = fgs[slot]
-            f.wait_all(pending[slot])  # the gather that last used this buffer set must have finished
-            if ev is not None:
-                ev[0].record(stream)
-            rend.enqueue(f.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
-            if ev is not None:
-                ev[1].record(stream)
-            pending[slot] = f.gather()
+        def measure(mode):
+            m = pt.MultiRenderer(devs, WIDTH, HEIGHT, spp, rng_mode=mode, variant=args.variant, persist_rng=True)
+            for _ in range(args.warmup):
+                m.render(frame.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye)
+            k_ms = 0.0
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                m.render(frame.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye)  # synchronous: frame assembled on return
+                k_ms += max(m.tile(r)["kernel_ms"] for r in range(n_gpus))
+            dt = time.perf_counter() - t0
+            return m, dt, k_ms / max(args.steps, 1) / 1e3
 
-        def sync():
-            for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
-                f.wait_all(pending[slot])
-                pending[slot] = []
+        m, elapsed, kernel_s = measure(rng_mode)
+        exchange = m.backend()
+        rb, re_ = m.tile(0)["rows"]
+        # a single-device renderer of rank 0's tile only to report which kernel that tile runs
+        probe = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=False)
+        ki = probe.kernel_info(len(spheres))
+        probe.destroy()
+        if args.dump:
+            import numpy as np
+
+            np.save(args.dump, frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+        alt = None
+        m.destroy()
+        tiling_note = f"rows/{n_gpus}, one process, {exchange}" if n_gpus > 1 else "single GPU (pt_mgpu_* with one device)"
+    else:
+        # ---- one process per GPU, torch.distributed (backend nccl = RCCL) --------------------------------------
+        # two frame/tile buffer sets: the gather of step k (RCCL stream) overlaps the render of step k+1
+        fgs = [tiling.FrameGather(WIDTH, HEIGHT, device) for _ in range(2 if world > 1 else 1)]
+        rb, re_ = fgs[0].rows
+        step_no = [0]
+
+        def measure(mode):
+            """W untimed + K timed frames with generator `mode`: (renderer, whole-job seconds, kernel seconds), max over ranks."""
+            rend = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=True)
+            pending = [[] for _ in fgs]
+
+            def step(ev=None):
+                slot = step_no[0] % len(fgs)
+                step_no[0] += 1
+                f = fgs[slot]
+                f.wait_all(pending[slot])  # the gather that last used this buffer set must have finished
+                if ev is not None:
+                    ev[0].record(stream)
+                rend.enqueue(f.tile.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye, stream=stream.cuda_stream)
+                if ev is not None:
+                    ev[1].record(stream)
+                pending[slot] = f.gather()
+
+            def sync():
+                for slot, f in enumerate(fgs):  # every outstanding gather completes inside the timed region
+                    f.wait_all(pending[slot])
+                    pending[slot] = []
+                if use_dist:
+                    dist.barrier()
+                torch.cuda.synchronize()
+
+            for _ in range(args.warmup):
+                step()
+            sync()
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step(events[k])
+            sync()
+            dt = time.perf_counter() - t0
+            k_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+            tmax = torch.tensor([dt, k_ms / 1e3], dtype=torch.float64, device=device)
             if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return rend, tmax[0].item(), tmax[1].item()
 
-        for _ in range(args.warmup):
-            step()
-        sync()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(events[k])
-        sync()
-        dt = time.perf_counter() - t0
-        k_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-        tmax = torch.tensor([dt, k_ms / 1e3], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return rend, tmax[0].item(), tmax[1].item()
+        renderer, elapsed, kernel_s = measure(rng_mode)
+        ki = renderer.kernel_info(len(spheres))
+        main_last_slot = (step_no[0] - 1) % len(fgs)
+        if rank == 0 and args.dump:
+            import numpy as np
 
-    renderer, elapsed, kernel_s = measure(rng_mode)
-    main_last_slot = (step_no[0] - 1) % len(fgs)
-    if rank == 0 and args.dump:
-        import numpy as np
-
-        np.save(args.dump, fgs[main_last_slot].frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
-    # the same measurement with the counter-based generator (north star: "a counter-based RNG in registers
-    # replacing curand"); reported beside the headline, which stays on the reference's XORWOW stream
-    alt = None
-    if args.rng == "xorwow" and not args.no_alt_rng:
-        r2, e2, k2 = measure(pt.RNG_PHILOX)
-        alt = {"rng": "philox4x32-10 (counter-based, no state traffic)", "value": round(WIDTH * HEIGHT * spp * args.steps / e2 / 1e6, 2),
-               "unit": "Msamples/s", "ms_per_step": round(e2 / args.steps * 1e3, 3), "kernel_ms": round(k2 * 1e3, 3),
-               "kernel_variant": r2.kernel_info(len(spheres))["variant"]}
-        r2.destroy()
+            np.save(args.dump, fgs[main_last_slot].frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+        # the same measurement with the counter-based generator (north star: "a counter-based RNG in registers
+        # replacing curand"); reported beside the headline, which stays on the reference's XORWOW stream
+        alt = None
+        if args.rng == "xorwow" and not args.no_alt_rng:
+            r2, e2, k2 = measure(pt.RNG_PHILOX)
+            alt = {"rng": "philox4x32-10 (counter-based, no state traffic)", "value": round(total_samples / e2 / 1e6, 2),
+                   "unit": "Msamples/s", "ms_per_step": round(e2 / args.steps * 1e3, 3), "kernel_ms": round(k2 * 1e3, 3),
+                   "kernel_variant": r2.kernel_info(len(spheres))["variant"]}
+            r2.destroy()
+        tiling_note = f"rows/{world}, one process per GPU, gather to rank 0 ({backend} grouped isend/irecv)" if world > 1 else "single GPU"
 
     if rank == 0:
-        total_samples = WIDTH * HEIGHT * spp * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         tile_pixels = (re_ - rb) * WIDTH
         achieved = BYTES_PER_PIXEL * tile_pixels / kernel_s / 1e9  # GB/s of algorithmic bytes, dominant kernel
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc) and world == 1 and spp == SPP:
-            try:
-                traffic = json.load(open(pmc)).get(f"{args.rng}_v{renderer.kernel_info(len(spheres))['variant']}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        valu = None
-        vr = os.path.join(ROOT, "profiles", "valu_roofline.json")
-        if os.path.exists(vr) and world == 1 and spp == SPP:
-            try:
-                rec = json.load(open(vr)).get(f"{args.rng}_v{renderer.kernel_info(len(spheres))['variant']}")
-                if rec:  # instruction count per launch is a property of the code; the rate uses THIS run's kernel time
-                    ach = rec["valu_insts_per_launch"] / kernel_s / 1e9
-                    valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(rec["peak_ginst_per_s"], 1),
-                            "unit": "G wave-instr/s", "frac": round(ach / rec["peak_ginst_per_s"], 4),
-                            "fp32_tflops": round(rec["fp32_tflops"] * rec["kernel_ms"] / (kernel_s * 1e3), 2),
-                            "fp64_tflops": round(rec["fp64_tflops"] * rec["kernel_ms"] / (kernel_s * 1e3), 2),
-                            "source": "profiles/valu_roofline.json (rocprofv3 SQ_INSTS_VALU*; peak = measured v_add_f32 issue rate)"}
-            except Exception:
-                valu = None
-        ki = renderer.kernel_info(len(spheres))
+        # counters that only a profiler can measure come from profiles/*.json -- but only if that profile was taken
+        # on THIS build of the library and this kernel (fingerprint + VGPR count); otherwise null, never stale numbers
+        traffic, valu, stale = None, None, None
+        if n_gpus == 1 and headline_config:
+            hrec, vrec, stale = profile_records(pt, args.config, args.rng, ki)
+            if hrec:
+                traffic = hrec.get("hbm_bytes_per_launch")
+            if vrec:  # instruction count per launch is a property of the code; the rate uses THIS run's kernel time
+                ach = vrec["valu_insts_per_launch"] / kernel_s / 1e9
+                valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+                        "frac": round(ach / VALU_PEAK_GINST, 4),
+                        "valu_insts_per_launch": vrec["valu_insts_per_launch"],
+                        "fp32_tflops": round(vrec["flops_fp32_per_launch"] / kernel_s / 1e12, 2),
+                        "fp64_tflops": round(vrec["flops_fp64_per_launch"] / kernel_s / 1e12, 2),
+                        "source": f"{vrec.get('source')} (rocprofv3 SQ_INSTS_VALU per launch / this run's kernel time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles "
+                                  "per wave64 instruction, MI355X_MICROARCH.md)"}
         out = {
-            "metric": "Msamples/s, 9-sphere Cornell box 1024x1024x1024spp",
+            "metric": f"Msamples/s, 9-sphere Cornell box {WIDTH}x{HEIGHT}x{spp}spp",
             "value": round(total_samples / elapsed / 1e6, 2),
             "unit": "Msamples/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -231,8 +351,9 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic (reference scene include/Scene.h:26-34, default camera, fixed seed)",
             "config": {
-                "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id (BASELINE.json configs[1])",
-                "tiling": f"rows/{world} + gather to rank 0 ({backend})" if world > 1 else "single GPU",
+                "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id ({cfg['name']})",
+                "tiling": tiling_note,
+                "engine": args.engine,
                 "kernel_variant": ki["variant"],
             },
             "roofline": {
@@ -248,13 +369,14 @@ def main():
                         "f32+f64), so the HBM fraction is <<1% by construction",
             },
             "valu_roofline": valu,
+            "profile_stale": stale,
             "counter_based_rng": alt,
-            "kernel_info": ki,
+            "kernel_info": dict(ki, fingerprint=pt.build_fingerprint()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not native and not args.no_cpu_baseline:
             oracle = ge.load_oracle()
             oracle.build()
-            out["cpu_baseline"] = cpu_baseline(oracle, spheres, basis, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(oracle, cfg, spheres, basis, args.cpu_rows)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -55,6 +55,16 @@ class RendererOpts(ctypes.Structure):
 
 
 LAYOUT_INTERLEAVED, LAYOUT_PLANAR = 0, 1
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER_COPY = 0, 1, 2
+
+
+class MgpuOpts(ctypes.Structure):
+    _fields_ = [
+        ("gather", ctypes.c_int32),
+        ("force_exchange", ctypes.c_int32),
+        ("timeout_ms", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
 
 
 class KernelInfo(ctypes.Structure):
@@ -76,6 +86,7 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes); this table is also what tests check against include/ptcore.h
 ABI = {
     "pt_abi_version": (ctypes.c_int, []),
+    "pt_build_fingerprint": (ctypes.c_char_p, []),
     "pt_last_error": (ctypes.c_char_p, []),
     "pt_set_device": (ctypes.c_int, [ctypes.c_int]),
     "pt_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -96,6 +107,14 @@ ABI = {
     "pt_renderer_get_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pt_renderer_set_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pt_renderer_kernel_info": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(KernelInfo)]),
+    "pt_mgpu_opts_default": (None, [ctypes.POINTER(MgpuOpts)]),
+    "pt_mgpu_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(RendererOpts), ctypes.POINTER(MgpuOpts), ctypes.POINTER(_vp)]),
+    "pt_mgpu_destroy": (ctypes.c_int, [_vp]),
+    "pt_mgpu_render": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _fp]),
+    "pt_mgpu_tile": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                    ctypes.POINTER(ctypes.c_int), _fp]),
+    "pt_mgpu_backend": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "pt_scene_cornell": (ctypes.c_int, [_vp]),
     "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
     "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
@@ -114,6 +133,10 @@ for _name, (_res, _args) in ABI.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export the ABI
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def build_fingerprint():
+    return lib.pt_build_fingerprint().decode()
 
 
 def check(rc):
@@ -312,6 +335,62 @@ class Renderer:
     def destroy(self):
         if self.handle:
             check(lib.pt_renderer_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """ctypes view of pt_mgpu: one frame row-tiled over several devices of this process (one host thread per
+    device inside the library, RCCL or peer-copy exchange to devices[0])."""
+
+    def __init__(self, devices, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
+                 persist_rng=True, variant=None, gather=None, force_exchange=None, timeout_ms=None):
+        o = RendererOpts()
+        lib.pt_renderer_opts_default(ctypes.byref(o))
+        o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
+        o.persist_rng = 1 if persist_rng else 0
+        if variant is not None:
+            o.variant = variant
+        mo = MgpuOpts()
+        lib.pt_mgpu_opts_default(ctypes.byref(mo))
+        if gather is not None:
+            mo.gather = gather
+        if force_exchange is not None:
+            mo.force_exchange = 1 if force_exchange else 0
+        if timeout_ms is not None:
+            mo.timeout_ms = timeout_ms
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = _vp()
+        check(lib.pt_mgpu_create(len(devices), devs, width, height, spp, threads_per_block, ctypes.byref(o), ctypes.byref(mo), ctypes.byref(h)))
+        self.handle = h.value
+        self.n, self.width, self.height, self.spp = len(devices), width, height, spp
+
+    def render(self, d_out, d_spheres, n_spheres, basis, eye=DEFAULT_EYE):
+        """Synchronous; returns end-to-end wall milliseconds (render + exchange)."""
+        _, b = _f32(basis, 12)
+        _, e = _f32(eye, 3)
+        ms = ctypes.c_float(0)
+        check(lib.pt_mgpu_render(self.handle, d_out, d_spheres, n_spheres, b, e, ctypes.byref(ms)))
+        return ms.value
+
+    def tile(self, rank):
+        dev, rb, re_, ms = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0)
+        check(lib.pt_mgpu_tile(self.handle, rank, ctypes.byref(dev), ctypes.byref(rb), ctypes.byref(re_), ctypes.byref(ms)))
+        return {"rank": rank, "device": dev.value, "rows": (rb.value, re_.value), "kernel_ms": ms.value}
+
+    def backend(self):
+        buf = ctypes.create_string_buffer(128)
+        check(lib.pt_mgpu_backend(self.handle, buf, 128))
+        return buf.value.decode()
+
+    def destroy(self):
+        if self.handle:
+            check(lib.pt_mgpu_destroy(self.handle))
             self.handle = None
 
     def __del__(self):

@@ -97,6 +97,10 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
 extern "C" {
 
 int pt_abi_version(void) { return PT_ABI_VERSION; }
+#ifndef PT_BUILD_FINGERPRINT
+#define PT_BUILD_FINGERPRINT "unknown"
+#endif
+const char* pt_build_fingerprint(void) { return PT_BUILD_FINGERPRINT; }
 const char* pt_last_error(void) { return g_err; }
 
 int pt_set_device(int device) {

@@ -7,7 +7,8 @@
 // stand-in for the interactive loop main.cu:146-177: N x Render() into the same device buffer),
 // --poses FILE (scripted fly-through: one "x y z yaw pitch" line per frame, the pose-list format of
 // collect_data.py:20-31; generator state carries over from frame to frame like the reference's
-// interactive mode, per-frame times are summarised).
+// interactive mode, per-frame times are summarised), --gpus N (the frame row-tiled over devices
+// --device .. --device+N-1 by one process: MultiRenderer / pt_mgpu_*, RCCL gather to the first device).
 #include <stdlib.h>
 #include <string.h>
 
@@ -20,6 +21,7 @@
 
 #include "Camera.h"
 #include "Denoiser.h"
+#include "MultiRenderer.h"
 #include "OutputBuffer.h"
 #include "Renderer.h"
 #include "Scene.h"
@@ -46,6 +48,7 @@ static void usage() {
                "  --spheres arg                 render a seeded random scene of N spheres\n"
                "  --frames arg                  render N frames back to back (headless interactive loop)\n"
                "  --poses arg                   fly-through: file with one 'x y z yaw pitch' line per frame\n"
+               "  --gpus arg                    row-tile the frame over N devices starting at --device (RCCL gather)\n"
                "  --preview arg                 also write the display-packed frame (Denoiser) as a binary PPM\n"
             << std::endl;
 }
@@ -61,7 +64,7 @@ int main(int argc, const char** argv) {
   bool denoising = false, interactive = false, noBitmap = false;
   std::string outputName = "output/out";
   std::string rng = "xorwow";
-  int maxBounces = 5, nSpheres = 0, frames = 1;
+  int maxBounces = 5, nSpheres = 0, frames = 1, gpus = 1;
   std::string posesFile, previewFile;
 
   for (int i = 1; i < argc; i++) {
@@ -92,6 +95,7 @@ int main(int argc, const char** argv) {
     else if (a == "--max-bounces") maxBounces = atoi(value("--max-bounces"));
     else if (a == "--spheres") nSpheres = atoi(value("--spheres"));
     else if (a == "--frames") frames = atoi(value("--frames"));
+    else if (a == "--gpus") gpus = atoi(value("--gpus"));
     else if (a == "--poses") posesFile = value("--poses");
     else if (a == "--preview") previewFile = value("--preview");
     else {
@@ -108,6 +112,12 @@ int main(int argc, const char** argv) {
   std::cout << "Threads per block: " << threadsPerBlock << std::endl;
   std::cout << "Samples per pixel: " << samplesPerPixel << std::endl;
   std::cout << "Using CUDA device: " << cudaDevice << std::endl;
+  const bool multi = gpus > 1 || (getenv("PT_FORCE_MGPU") && atoi(getenv("PT_FORCE_MGPU")) != 0);
+  if (gpus < 1) {
+    std::cerr << "ERROR: --gpus must be at least 1" << std::endl;
+    return 1;
+  }
+  if (multi) std::cout << "Row-tiled over " << gpus << " device(s) starting at " << cudaDevice << std::endl;
   if (!interactive)
     std::cout << "Output file prefix: " << outputName << std::endl;
   else
@@ -129,7 +139,19 @@ int main(int argc, const char** argv) {
   pt_renderer_opts_default(&opts);
   opts.max_bounces = maxBounces;
   opts.rng_mode = rng == "philox" ? PT_RNG_PHILOX : PT_RNG_XORWOW;
-  Renderer renderer(width, height, samplesPerPixel, threadsPerBlock, opts);
+  // one device: the reference's Renderer; several: the same interface over pt_mgpu_* (frame and scene stay on
+  // the first device, where main.cu has them)
+  Renderer* single = NULL;
+  MultiRenderer* tiled = NULL;
+  if (multi) {
+    std::vector<int> devices;
+    for (int g = 0; g < gpus; g++) devices.push_back(cudaDevice + g);
+    tiled = new MultiRenderer(devices, width, height, samplesPerPixel, threadsPerBlock, &opts);
+    std::cout << "Exchange: " << tiled->Backend() << std::endl;
+  } else {
+    single = new Renderer(width, height, samplesPerPixel, threadsPerBlock, opts);
+  }
+  auto render = [&](OutputBuffer b, const Scene& s, const Camera& c) { return tiled ? tiled->Render(b, s, c) : single->Render(b, s, c); };
   Camera camera(cameraPos[0], cameraPos[1], cameraPos[2], cameraView[0], cameraView[1]);
 
   // allocate output buffer (main.cu:131-139)
@@ -153,7 +175,7 @@ int main(int argc, const char** argv) {
       float x, y, z, yaw, pitch;
       if (!(ls >> x >> y >> z >> yaw >> pitch)) continue;
       Camera pose(x, y, z, yaw, pitch);
-      renderTime = renderer.Render(d_buffer, scene, pose);
+      renderTime = render(d_buffer, scene, pose);
       times.push_back(renderTime);
     }
     if (times.empty()) {
@@ -168,9 +190,14 @@ int main(int argc, const char** argv) {
               << sorted[sorted.size() / 2] << "ms, min " << sorted.front() << "ms, max " << sorted.back() << "ms ("
               << 1000.0 * times.size() / sum << " fps)" << std::endl;
   } else {
-    for (int f = 0; f < frames; f++) renderTime = renderer.Render(d_buffer, scene, camera);
+    for (int f = 0; f < frames; f++) renderTime = render(d_buffer, scene, camera);
   }
   std::cout << "Render completed in " << renderTime << "ms (" << 1000.0f / renderTime << " fps)" << std::endl;
+  if (tiled) {
+    std::cout << "Tile kernel times:";
+    for (int g = 0; g < gpus; g++) std::cout << " " << tiled->TileKernelMs(g) << "ms";
+    std::cout << std::endl;
+  }
   std::cout << std::endl;
   if (!previewFile.empty()) {
     // what the interactive mode would put on screen (main.cu:175-176): Denoiser packs the colour
@@ -202,6 +229,8 @@ int main(int argc, const char** argv) {
   buffer.SaveEXR(outputName + ".exr");
   if (!noBitmap) buffer.SaveBitmaps(outputName);
   buffer.FreeCPU();
+  delete single;
+  delete tiled;
   d_buffer.FreeGPU();
   scene.Free();
   return 0;

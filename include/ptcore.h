@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 enum {
   PT_OK = 0,
@@ -41,7 +41,9 @@ enum {
   PT_EHIP = -2,      /* a HIP runtime call failed (message has hipGetErrorString) */
   PT_ENODEVICE = -3, /* no HIP device visible                                */
   PT_ENOMEM = -4,    /* host allocation failed                               */
-  PT_ELIMIT = -5     /* scene does not fit the kernel's LDS staging budget   */
+  PT_ELIMIT = -5,    /* scene does not fit the kernel's LDS staging budget   */
+  PT_ECOMM = -6,     /* RCCL could not be loaded or a collective call failed (multi-GPU) */
+  PT_ETIMEOUT = -7   /* a multi-GPU frame did not complete in time; the exchange was aborted */
 };
 
 /* struct Sphere, include/Scene.h:7-14 -- same 40-byte layout, so a reference
@@ -82,6 +84,9 @@ typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's pri
 
 /* ---- library / device -------------------------------------------------------------- */
 int pt_abi_version(void);
+/* 16 hex digits identifying the compiled sources + flags of this library (csrc/Makefile): measured
+ * counters under profiles/ name the build they belong to. */
+const char* pt_build_fingerprint(void);
 const char* pt_last_error(void);
 /* cudaSetDevice(cudaDevice), src/main.cu:86 */
 int pt_set_device(int device);
@@ -154,6 +159,53 @@ typedef struct pt_kernel_info {
   int32_t variant;      /* the variant the next launch will use (resolves the automatic choice) */
 } pt_kernel_info;
 int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info);
+
+/* ---- one frame over several GPUs of one node ------------------------------------------------- */
+/* The reference selects ONE device per process (cudaSetDevice(cudaDevice), src/main.cu:86) and its
+ * Renderer covers the whole image with one launch (Renderer.h:29-33,69).  pt_mgpu_* is the same
+ * Renderer boundary over N devices: the image is cut into N contiguous row blocks (pixels are
+ * independent and every generator is keyed on the global pixel id, pathtrace.cu:206,265, so the
+ * result does not depend on the cut), one host thread per device renders its block, and ONE
+ * exchange step per frame places the blocks in the caller's frame on devices[0]: grouped RCCL
+ * ncclRecv x (N-1) on the root straight into the frame at the tile offsets | one ncclSend per peer.
+ * Single process, no launcher; RCCL is dlopen'ed on first use. */
+enum {
+  PT_GATHER_AUTO = 0,      /* RCCL between distinct devices, peer copies if ranks share a device   */
+  PT_GATHER_RCCL = 1,      /* ncclGroupStart{ncclRecv x (N-1) | ncclSend}ncclGroupEnd over xGMI     */
+  PT_GATHER_PEER_COPY = 2  /* hipMemcpyPeerAsync of each tile on its own stream (SDMA over xGMI)    */
+};
+typedef struct pt_mgpu_opts {
+  int32_t gather;          /* PT_GATHER_*                                                          */
+  int32_t force_exchange;  /* 1: even the root's tile is rendered into a tile buffer and travels   */
+                           /*    through the exchange step (self send/recv): exercises the whole   */
+                           /*    multi-GPU path on a single-GPU machine.  Env PT_FORCE_MGPU=1.      */
+  int32_t timeout_ms;      /* a frame not complete after this long fails with PT_ETIMEOUT and the  */
+                           /*    communicator is aborted (0 = wait forever).  Env PT_MGPU_TIMEOUT_MS, default 60000 */
+  int32_t reserved;
+} pt_mgpu_opts;
+typedef struct pt_mgpu pt_mgpu; /* opaque */
+
+/* Defaults, with the environment overrides PT_FORCE_MGPU, PT_MGPU_TIMEOUT_MS, PT_MGPU_GATHER=rccl|copy. */
+void pt_mgpu_opts_default(pt_mgpu_opts* opts);
+/* Renderer::Renderer over n_gpus devices (devices == NULL: 0..n_gpus-1; devices[0] is the root that
+ * owns the caller's frame and scene).  opts as for pt_renderer_create, with row_begin = row_end = 0;
+ * mopts may be NULL.  Creates per device: a renderer for its row block (generator state included),
+ * a stream, a tile buffer; and one RCCL communicator over all of them (ncclCommInitAll). */
+int pt_mgpu_create(int n_gpus, const int* devices, int width, int height, int samples_per_pixel,
+                   int threads_per_block, const pt_renderer_opts* opts, const pt_mgpu_opts* mopts,
+                   pt_mgpu** out);
+int pt_mgpu_destroy(pt_mgpu* m);
+/* Renderer::Render (Renderer.h:55-76) for the whole frame: d_out ([height][width][14]) and
+ * d_spheres live on devices[0] and must be complete (the call does not order itself after the
+ * caller's streams); the scene is replicated to the other devices by peer copies (360 B .. 40 KB).
+ * Synchronous: returns when the frame is assembled.  *ms_out = end-to-end wall milliseconds
+ * (render + exchange); per-tile kernel times: pt_mgpu_tile. */
+int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_spheres,
+                   const float basis[12], const float eye[3], float* ms_out);
+/* Row block, device and last kernel time of a rank (any out pointer may be NULL). */
+int pt_mgpu_tile(pt_mgpu* m, int rank, int* device, int* row_begin, int* row_end, float* kernel_ms);
+/* Name of the exchange backend in use (for logs / bench). */
+int pt_mgpu_backend(pt_mgpu* m, char* name, size_t name_len);
 
 /* ---- display packing ------------------------------------------------------------------- */
 /* Denoiser::Denoise -> denoise_kernel (include/Denoiser.h:29-52, src/denoise.cu:9-29): despite the

@@ -58,6 +58,23 @@ def build(force=False):
     return _LIB_PATH
 
 
+_NATIVE_PATH = os.path.join(_HERE, "_native", "libpt_oracle_native.so")
+_native = None
+
+
+def native_lib():
+    """The same source built `-O3 -march=native` (gcc's default FP contraction, the host's vector ISA): the second
+    CPU-baseline figure of SURVEY.md 8(d).  TIMING ONLY -- it does not follow the numeric contract, so it is never
+    compared with anything.  -march=native binds it to the machine that compiled it: built where it runs."""
+    global _native
+    if _native is None:
+        os.makedirs(os.path.dirname(_NATIVE_PATH), exist_ok=True)
+        subprocess.check_call(["gcc", "-std=c99", "-O3", "-march=native", "-fPIC", "-pthread", "-shared", "-o", _NATIVE_PATH,
+                               os.path.join(_HERE, "pt_oracle.c"), "-lm", "-pthread"])
+        _native = _bind(ctypes.CDLL(_NATIVE_PATH))
+    return _native
+
+
 _lib = None
 
 
@@ -66,33 +83,36 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = ctypes.CDLL(_LIB_PATH)
-        fp = ctypes.POINTER(ctypes.c_float)
-        up = ctypes.POINTER(ctypes.c_uint32)
-        L.pto_render.restype = ctypes.c_int
-        L.pto_render.argtypes = [ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int, fp, fp, fp, up, ctypes.c_int]
-        L.pto_setup_random.restype = None
-        L.pto_setup_random.argtypes = [ctypes.POINTER(Params), up]
-        L.pto_scene_cornell.restype = None
-        L.pto_scene_cornell.argtypes = [ctypes.c_void_p]
-        L.pto_camera_basis.restype = None
-        L.pto_camera_basis.argtypes = [fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, fp]
-        L.pto_display_pack.restype = None
-        L.pto_display_pack.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
-        L.pto_xorwow_init.restype = None
-        L.pto_xorwow_init.argtypes = [ctypes.c_uint64, up]
-        L.pto_xorwow_next.restype = ctypes.c_uint32
-        L.pto_xorwow_next.argtypes = [up]
-        L.pto_uniform_from_u32.restype = ctypes.c_float
-        L.pto_uniform_from_u32.argtypes = [ctypes.c_uint32]
-        L.pto_philox4x32_10.restype = None
-        L.pto_philox4x32_10.argtypes = [up, up, up]
-        L.pto_sincos.restype = None
-        L.pto_sincos.argtypes = [ctypes.c_float, fp, fp]
-        L.pto_intersect_sphere.restype = ctypes.c_int
-        L.pto_intersect_sphere.argtypes = [fp, fp, ctypes.c_void_p, fp]
-        _lib = L
+        _lib = _bind(ctypes.CDLL(_LIB_PATH))
     return _lib
+
+
+def _bind(L):
+    fp = ctypes.POINTER(ctypes.c_float)
+    up = ctypes.POINTER(ctypes.c_uint32)
+    L.pto_render.restype = ctypes.c_int
+    L.pto_render.argtypes = [ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int, fp, fp, fp, up, ctypes.c_int]
+    L.pto_setup_random.restype = None
+    L.pto_setup_random.argtypes = [ctypes.POINTER(Params), up]
+    L.pto_scene_cornell.restype = None
+    L.pto_scene_cornell.argtypes = [ctypes.c_void_p]
+    L.pto_camera_basis.restype = None
+    L.pto_camera_basis.argtypes = [fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, fp]
+    L.pto_display_pack.restype = None
+    L.pto_display_pack.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
+    L.pto_xorwow_init.restype = None
+    L.pto_xorwow_init.argtypes = [ctypes.c_uint64, up]
+    L.pto_xorwow_next.restype = ctypes.c_uint32
+    L.pto_xorwow_next.argtypes = [up]
+    L.pto_uniform_from_u32.restype = ctypes.c_float
+    L.pto_uniform_from_u32.argtypes = [ctypes.c_uint32]
+    L.pto_philox4x32_10.restype = None
+    L.pto_philox4x32_10.argtypes = [up, up, up]
+    L.pto_sincos.restype = None
+    L.pto_sincos.argtypes = [ctypes.c_float, fp, fp]
+    L.pto_intersect_sphere.restype = ctypes.c_int
+    L.pto_intersect_sphere.argtypes = [fp, fp, ctypes.c_void_p, fp]
+    return L
 
 
 def _fp(a):
@@ -117,8 +137,9 @@ def camera_basis(pos=(50.0, 52.0, 295.6), yaw=-90.0, pitch=0.0, w=256, h=256):
 
 
 def render(width, height, spp, spheres=None, basis=None, eye=(50.0, 52.0, 295.6), *, row_begin=0,
-           row_end=None, max_bounces=5, rng_mode=RNG_XORWOW, seed=0, frame=0, rng_state=None, threads=None):
-    """Render rows [row_begin,row_end) -> float32 array [rows][width][14]."""
+           row_end=None, max_bounces=5, rng_mode=RNG_XORWOW, seed=0, frame=0, rng_state=None, threads=None, native=False):
+    """Render rows [row_begin,row_end) -> float32 array [rows][width][14].  native=True: the -O3 -march=native
+    build (timing only, not the contract's arithmetic)."""
     if row_end is None:
         row_end = height
     if spheres is None:
@@ -136,7 +157,7 @@ def render(width, height, spp, spheres=None, basis=None, eye=(50.0, 52.0, 295.6)
     if rng_state is not None:
         assert rng_state.dtype == np.uint32 and rng_state.size == (row_end - row_begin) * width * 6
         st = _up(rng_state)
-    rc = lib().pto_render(ctypes.byref(p), spheres.ctypes.data, len(spheres), _fp(basis), _fp(eye), _fp(out), st,
+    rc = (native_lib() if native else lib()).pto_render(ctypes.byref(p), spheres.ctypes.data, len(spheres), _fp(basis), _fp(eye), _fp(out), st,
                           threads)
     if rc != 0:
         raise ValueError("pto_render: bad arguments")

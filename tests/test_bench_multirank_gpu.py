@@ -39,3 +39,20 @@ def test_bench_single_and_two_ranks_agree(gpu, tmp_path):
         assert "workload" in j["config"]
     a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # tiling + gather change no pixel, even on frame 3
+    # the form the driver records -- `python bench.py --gpus N`, no launcher: bench.py starts its own ranks
+    three = _run([sys.executable, "bench.py", "--gpus", "3", "--dump", str(tmp_path / "three.npy")] + common,
+                 env={"PT_BENCH_SHARED_GPU": "1", "PT_BENCH_BACKEND": "gloo"})
+    assert three["n_gpus"] == 3 and "rows/3" in three["config"]["tiling"]
+    assert np.array_equal(a.view(np.uint32), np.load(tmp_path / "three.npy").view(np.uint32))
+    # one process, libptcore's own multi-GPU entry (pt_mgpu_*), ranks sharing GPU 0
+    nat = _run([sys.executable, "bench.py", "--gpus", "2", "--engine", "native", "--dump", str(tmp_path / "nat.npy")] + common,
+               env={"PT_BENCH_SHARED_GPU": "1", "PT_FORCE_MGPU": "1"})
+    assert nat["n_gpus"] == 2 and nat["config"]["engine"] == "native" and "hipMemcpyPeerAsync" in nat["config"]["tiling"]
+    assert np.array_equal(a.view(np.uint32), np.load(tmp_path / "nat.npy").view(np.uint32))
+
+
+def test_bench_config3_line(gpu):
+    """--config cfg3 (4096 x 4096 x 64 spp, BASELINE.json configs[2]) runs on one GPU and names its workload."""
+    j = _run([sys.executable, "bench.py", "--config", "cfg3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt-rng"])
+    assert "4096x4096" in j["metric"] and "configs[2]" in j["config"]["workload"] and j["n_gpus"] == 1
+    assert 40 < j["ms_per_step"] < 200 and j["roofline"]["kernel_ms"] > 0

@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol(pt):
 
 
 def test_abi_version_and_struct_layout(pt):
-    assert pt.lib.pt_abi_version() == 2
+    assert pt.lib.pt_abi_version() == 3
     assert pt.SPHERE_DTYPE.itemsize == 40          # include/Scene.h:7-14
-    assert ctypes.sizeof(pt.RendererOpts) == 40
+    assert ctypes.sizeof(pt.RendererOpts) == 40 and ctypes.sizeof(pt.MgpuOpts) == 16
     o = pt.RendererOpts()
     pt.lib.pt_renderer_opts_default(ctypes.byref(o))
     assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant, o.layout) == (5, 0, 0, 1, -1, pt.LAYOUT_INTERLEAVED)
@@ -92,6 +92,27 @@ def test_compute_fails_loudly_without_gpu(pt):
     assert e.value.code in (-2, -3) and "device" in str(e.value).lower()
     with pytest.raises(pt.PtError):
         pt.DeviceBuffer(1024)
+
+
+def test_mgpu_fails_loudly_without_gpu_and_validates_arguments(pt):
+    """The multi-GPU entry has no fallback either, and rejects nonsense before touching a device."""
+    with pytest.raises(pt.PtError) as e:
+        pt.MultiRenderer([], 16, 16, 1)
+    assert e.value.code == -1
+    with pytest.raises(pt.PtError) as e:
+        pt.MultiRenderer([0], 0, 16, 1)
+    assert e.value.code == -1
+    try:
+        n = pt.device_count()
+    except pt.PtError:
+        n = 0
+    if n == 0:
+        with pytest.raises(pt.PtError) as e:
+            pt.MultiRenderer([0, 1], 16, 16, 1)
+        assert e.value.code == -3 and "device" in str(e.value).lower()
+    mo = pt.MgpuOpts()
+    pt.lib.pt_mgpu_opts_default(ctypes.byref(mo))
+    assert (mo.gather, mo.timeout_ms) == (pt.GATHER_AUTO, 60000)
 
 
 def _build_abi_example(tmp_path):

@@ -1,0 +1,129 @@
+"""pt_mgpu_* (include/ptcore.h): one frame row-tiled over several devices by ONE process -- one host thread
+per device inside libptcore, grouped RCCL send/recv (or peer copies) into the root's frame.  The driver's
+test box has one GPU, so the multi-rank machinery is exercised with ranks SHARING device 0 (peer-copy
+exchange; RCCL refuses duplicate devices in one communicator) and with a one-rank RCCL communicator whose
+tile is forced through the exchange (self send/recv: ncclCommInitAll, ncclGroupStart/End, ncclSend, ncclRecv
+all really run).  With two or more GPUs visible the real thing runs too.  Frames must equal the
+single-renderer frame and the oracle bit for bit: tiling and exchange may not change a pixel."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_parity_gpu import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_mgpu(pt, devices, size, spp, frames=1, scene=None, **kw):
+    scene = pt.scene_cornell() if scene is None else scene
+    basis = pt.camera_basis(width=size, height=size)
+    m = pt.MultiRenderer(devices, size, size, spp, **kw)
+    d_scene, n = pt.upload_scene(scene)
+    d_out = pt.DeviceBuffer(size * size * 56)
+    pt.check(pt.lib.pt_memset(d_out.ptr, 0xFF, size * size * 56))
+    pt.check(pt.lib.pt_device_synchronize())
+    out = []
+    for _ in range(frames):
+        ms = m.render(d_out.ptr, d_scene.ptr, n, basis)
+        assert ms > 0
+        out.append(d_out.download(np.float32, (size, size, 14)))
+    info = {"backend": m.backend(), "tiles": [m.tile(r) for r in range(len(devices))]}
+    m.destroy()
+    return out, info
+
+
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_ranks_sharing_one_device_peer_copy_exchange(pt, oracle, gpu, rng):
+    """3 ranks (ragged: 100 rows -> 34/33/33) on device 0, every tile rendered into its own buffer and moved
+    into the frame by the exchange step; two frames (persisted generator state per tile)."""
+    size, spp = 100, 4
+    frames, info = _render_mgpu(pt, [0, 0, 0], size, spp, frames=2, rng_mode=rng, force_exchange=True)
+    assert info["backend"] == "hipMemcpyPeerAsync"
+    assert [t["rows"] for t in info["tiles"]] == [(0, 34), (34, 67), (67, 100)]
+    assert all(t["kernel_ms"] > 0 for t in info["tiles"])
+    basis = pt.camera_basis(width=size, height=size)
+    st = oracle.setup_random(size, size) if rng == 0 else None
+    for f, img in enumerate(frames):
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng, rng_state=st, frame=f)
+        assert_bit_exact(img, ref, f"3 ranks on one device, frame {f}")
+
+
+def test_in_place_tiles_without_exchange(pt, oracle, gpu):
+    """Ranks on the root's device render straight into the frame (no exchange needed): 5 ranks, 64 rows."""
+    frames, info = _render_mgpu(pt, [0] * 5, 64, 3)
+    ref = oracle.render(64, 64, 3, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=64, height=64))
+    assert_bit_exact(frames[0], ref, "5 in-place tiles")
+
+
+def test_more_ranks_than_rows(pt, oracle, gpu):
+    frames, info = _render_mgpu(pt, [0] * 6, 4, 2, force_exchange=True)
+    assert [t["rows"][1] - t["rows"][0] for t in info["tiles"]] == [1, 1, 1, 1, 0, 0]
+    ref = oracle.render(4, 4, 2, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=4, height=4))
+    assert_bit_exact(frames[0], ref, "6 ranks, 4 rows")
+
+
+def test_rccl_exchange_on_one_gpu_self_send_recv(pt, oracle, gpu):
+    """PT_FORCE_MGPU semantics: a one-rank RCCL communicator; the tile is rendered into the tile buffer and
+    placed in the frame by ncclSend/ncclRecv to self inside one group.  1000-sphere scene as well (the scene
+    replica path is not taken on the root, the grid kernel is)."""
+    size, spp = 96, 4
+    frames, info = _render_mgpu(pt, [0], size, spp, frames=2, force_exchange=True, gather=pt.GATHER_RCCL, timeout_ms=30000)
+    assert info["backend"].startswith("rccl")
+    basis = pt.camera_basis(width=size, height=size)
+    st = oracle.setup_random(size, size)
+    for f, img in enumerate(frames):
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_state=st)
+        assert_bit_exact(img, ref, f"rccl self exchange frame {f}")
+    scene = pt.scene_random(400, seed=5)
+    frames, _ = _render_mgpu(pt, [0], 48, 2, scene=scene, force_exchange=True, gather=pt.GATHER_RCCL, timeout_ms=30000)
+    assert_bit_exact(frames[0], oracle.render(48, 48, 2, spheres=scene, basis=pt.camera_basis(width=48, height=48)), "rccl, 400 spheres")
+
+
+def test_real_multi_gpu_rccl_gather(pt, oracle, gpu):
+    """Distinct devices, RCCL over xGMI: only where the box has them (the driver's test box has one GPU)."""
+    n = pt.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible")
+    n = min(n, 8)
+    size, spp = 256, 8
+    frames, info = _render_mgpu(pt, list(range(n)), size, spp, frames=2)
+    assert info["backend"].startswith("rccl")
+    basis = pt.camera_basis(width=size, height=size)
+    st = oracle.setup_random(size, size)
+    for f, img in enumerate(frames):
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_state=st)
+        assert_bit_exact(img, ref, f"{n} GPUs frame {f}")
+
+
+def test_argument_errors(pt, gpu):
+    with pytest.raises(pt.PtError) as e:
+        pt.MultiRenderer([0, 99], 16, 16, 1)
+    assert e.value.code == -1 and "device 99" in str(e.value)
+    with pytest.raises(pt.PtError) as e:
+        pt.MultiRenderer([0, 0], 16, 16, 1, gather=pt.GATHER_RCCL)
+    assert e.value.code == -1 and "distinct" in str(e.value)
+    with pytest.raises(pt.PtError):
+        pt.MultiRenderer([], 16, 16, 1)
+
+
+def test_cli_gpus_flag_forced_exchange(pt, oracle, gpu, tmp_path):
+    """pathtrace --gpus 1 with PT_FORCE_MGPU=1: MultiRenderer + RCCL exchange behind the reference's CLI;
+    the saved EXR must hold the oracle's frame."""
+    from conftest import ROOT
+    from test_parity_gpu import _read_feature_exr
+
+    exe = os.path.join(ROOT, "cuda-pathtrace_amd", "pathtrace")
+    out = str(tmp_path / "tiled")
+    env = dict(os.environ, PT_FORCE_MGPU="1", PT_MGPU_TIMEOUT_MS="30000")
+    res = subprocess.run([exe, "--size", "64", "-s", "4", "--gpus", "1", "--nobitmap", "-o", out], capture_output=True, text=True,
+                         timeout=180, env=env)
+    assert res.returncode == 0, res.stderr
+    assert "Row-tiled over 1 device(s)" in res.stdout and "Exchange: rccl" in res.stdout and "Tile kernel times:" in res.stdout
+    names, planes = _read_feature_exr(out + ".exr")
+    ref = oracle.render(64, 64, 4, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=64, height=64))
+    for nm, ch in (("Color.R", 0), ("Normal.Y", 4), ("DepthVar.Z", 13)):
+        assert np.array_equal(planes[names.index(nm)].view(np.uint32), ref[..., ch].view(np.uint32)), nm
+    bad = subprocess.run([exe, "--size", "16", "-s", "1", "--gpus", "64", "-o", out], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "GPUassert:" in bad.stderr

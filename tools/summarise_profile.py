@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", rnd)
@@ -48,26 +48,22 @@ if counters.get("SQ_BUSY_CYCLES") and counters.get("SQ_ACTIVE_INST_VALU"):
         "wait_inst_any_over_wave_cycles": counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
         "wait_any_over_wave_cycles": counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1),
     }
-# VALU issue utilisation: instruction classes x the issue costs measured by tools/ubench/valu_cost
-# (units of one v_add_f32 = UNIT_NS per wave-instruction per SIMD at full occupancy)
-UNIT_NS = 1.125
-COST = {"SQ_INSTS_VALU_ADD_F32": 1.0, "SQ_INSTS_VALU_MUL_F32": 1.0, "SQ_INSTS_VALU_FMA_F32": 1.42, "SQ_INSTS_VALU_TRANS_F32": 3.0,
-        "SQ_INSTS_VALU_ADD_F64": 1.53, "SQ_INSTS_VALU_MUL_F64": 1.58, "SQ_INSTS_VALU_FMA_F64": 1.60, "SQ_INSTS_VALU_TRANS_F64": 6.0,
-        "SQ_INSTS_VALU_CVT": 1.52, "SQ_INSTS_VALU_INT32": 1.3, "SQ_INSTS_VALU_INT64": 1.55}
-if all(k in counters for k in COST) and "SQ_INSTS_VALU" in counters and st:
-    classified = sum(counters[k] for k in COST)
-    other = max(counters["SQ_INSTS_VALU"] - classified, 0.0)  # compares, selects, min/max, moves, bit ops
-    units = sum(counters[k] * c for k, c in COST.items()) + other * 1.35
+# VALU issue roofline: wave-instructions per second against the guide's peak (MI355X_MICROARCH.md: a wave64 VALU
+# instruction holds its SIMD-32 for 2 cycles -> 1024 SIMDs x 2.4 GHz / 2).  No per-class weights: a model built on
+# them once produced a "utilisation" above 1; what is reported is count / time / peak, nothing else.
+VALU_PEAK = 256 * 4 * 2.4e9 / 2.0
+MIX = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_ADD_F64",
+       "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32",
+       "SQ_INSTS_VALU_INT64"]
+if "SQ_INSTS_VALU" in counters and st:
     kern = next(r for r in out["kernel_stats"] if "pixel_kernel" in r["Name"])
     t_ns = float(kern["AverageNs"])
-    simds = 256 * 4
     out["valu"] = {
-        "insts_per_launch": counters["SQ_INSTS_VALU"], "classified_fraction": classified / counters["SQ_INSTS_VALU"],
-        "issue_units_per_launch": units, "unit_ns": UNIT_NS, "simds": simds,
-        "issue_bound_ms": units * UNIT_NS / simds / 1e6, "kernel_ms": t_ns / 1e6,
-        "issue_utilisation": units * UNIT_NS / simds / t_ns,
+        "insts_per_launch": counters["SQ_INSTS_VALU"], "kernel_ms": t_ns / 1e6,
+        "achieved_ginst_per_s": counters["SQ_INSTS_VALU"] / t_ns, "peak_ginst_per_s": VALU_PEAK / 1e9,
+        "frac": counters["SQ_INSTS_VALU"] / (t_ns * 1e-9) / VALU_PEAK,
         "flops_fp32": counters.get("SQ_INSTS_VALU_FLOPS_FP32"), "flops_fp64": counters.get("SQ_INSTS_VALU_FLOPS_FP64"),
-        "mix": {k.replace("SQ_INSTS_VALU_", ""): counters[k] for k in COST},
+        "mix": {k.replace("SQ_INSTS_VALU_", ""): counters[k] for k in MIX if k in counters},
     }
 for log in ("stats.log",):
     p = os.path.join(src, log)
@@ -75,5 +71,8 @@ for log in ("stats.log",):
         for line in open(p):
             if line.startswith('{"metric"'):
                 out["bench_line_under_profiler"] = json.loads(line)
+                ki = out["bench_line_under_profiler"].get("kernel_info", {})
+                out["fingerprint"] = ki.get("fingerprint")  # the build these counters belong to
+                out["num_vgprs"] = ki.get("num_vgprs")
 json.dump(out, open(os.path.join(dst, f"{tag}.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in out if k != "bench_line_under_profiler"}, indent=1))
