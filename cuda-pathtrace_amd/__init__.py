@@ -17,8 +17,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PT_LIB_OVERRIDE: A/B experiments with an alternative build of the same library (tools/ab_tiles.py)
+# PT_LIB_OVERRIDE: another build of the same library -- A/B experiments (tools/ab_tiles.py) and the lab build
+# libptcore_lab.so (experimental kernel variants + pt_debug_* diagnostics; __graft_entry__.load_lab())
 LIB_PATH = os.environ.get("PT_LIB_OVERRIDE") or os.path.join(_HERE, "libptcore.so")
+LAB_LIB_PATH = os.path.join(_HERE, "libptcore_lab.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 if not os.path.exists(LIB_PATH):
@@ -118,7 +120,11 @@ ABI = {
     "pt_scene_cornell": (ctypes.c_int, [_vp]),
     "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
     "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
+    "pt_camera_basis_up": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, _fp, ctypes.c_int, ctypes.c_int, _fp]),
     "pt_display_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+}
+# include/ptcore_lab.h: only libptcore_lab.so exports these
+LAB_ABI = {
     "pt_debug_unary_map": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "pt_debug_unary_compare": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
@@ -133,6 +139,29 @@ for _name, (_res, _args) in ABI.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export the ABI
     _fn.restype = _res
     _fn.argtypes = _args
+IS_LAB = hasattr(lib, "pt_debug_unary_map")
+if IS_LAB:
+    for _name, (_res, _args) in LAB_ABI.items():
+        _fn = getattr(lib, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
+
+
+def variants():
+    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 10, 11; lab: 0..11)."""
+    out = []
+    o = RendererOpts()
+    for v in range(12):
+        lib.pt_renderer_opts_default(ctypes.byref(o))
+        o.variant = v
+        h = _vp()
+        rc = lib.pt_renderer_create(8, 8, 1, 8, ctypes.byref(o), ctypes.byref(h))
+        if rc == 0:
+            lib.pt_renderer_destroy(h)
+            out.append(v)
+        elif rc != -1:  # anything but "not in this build" is a real failure (no device ...)
+            check(rc)
+    return out
 
 
 def build_fingerprint():
@@ -165,10 +194,14 @@ def scene_random(n, seed=0, with_walls=True):
 DEFAULT_EYE = (50.0, 52.0, 295.6)  # src/main.cu:24
 
 
-def camera_basis(pos=DEFAULT_EYE, yaw=-90.0, pitch=0.0, width=512, height=512):
+def camera_basis(pos=DEFAULT_EYE, yaw=-90.0, pitch=0.0, width=512, height=512, world_up=None):
     p, pp = _f32(pos, 3)
     out = np.zeros(12, dtype=np.float32)
-    check(lib.pt_camera_basis(pp, yaw, pitch, width, height, out.ctypes.data_as(_fp)))
+    if world_up is None:
+        check(lib.pt_camera_basis(pp, yaw, pitch, width, height, out.ctypes.data_as(_fp)))
+    else:
+        u, up = _f32(world_up, 3)
+        check(lib.pt_camera_basis_up(pp, yaw, pitch, up, width, height, out.ctypes.data_as(_fp)))
     return out
 
 

@@ -193,8 +193,9 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
     return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
   if (o.layout != PT_LAYOUT_INTERLEAVED && o.layout != PT_LAYOUT_PLANAR) return pt_fail(PT_EINVAL, "pt_renderer_create: layout %d", o.layout);
-  if (o.variant != PT_VARIANT_AUTO && (o.variant < 0 || o.variant >= pt_kernel_num_variants()))
-    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d (have %d)", o.variant, pt_kernel_num_variants());
+  if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
+    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11; "
+                              "the experiments 1-5, 7, 9 live in libptcore_lab.so)", o.variant);
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
 
@@ -409,18 +410,6 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;
   info->max_spheres = pt_kernel_max_spheres(variant);
-  return PT_OK;
-}
-
-// diagnostics: build variant 11's grid for a scene and return its 16-word header
-int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]) {
-  if (!d_spheres || !header_out || n_spheres < 1) return pt_fail(PT_EINVAL, "pt_debug_grid_header: bad arguments");
-  uint32_t* d = nullptr;
-  PT_HIP(hipMalloc((void**)&d, pt_kernel_accel_bytes()));
-  hipError_t e = pt_launch_build_grid(d_spheres, n_spheres, d, nullptr);
-  if (e == hipSuccess) e = hipMemcpy(header_out, d, 64, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
-  PT_HIP(e);
   return PT_OK;
 }
 

@@ -1,4 +1,4 @@
-// pt_debug.hip -- the display packer (denoise_kernel) and diagnostic entry points (include/ptcore.h "diagnostics"): evaluate the
+// pt_debug.hip -- LAB LIBRARY ONLY (libptcore_lab.so, include/ptcore_lab.h): diagnostic entry points that evaluate the
 // device-side scalar building blocks elementwise, and compare two of them over a range of
 // float bit patterns.  Used by the tests to (1) check the device definitions of sin/cos,
 // sqrt, 1/sqrt against the CPU oracle on dense samples and (2) PROVE by exhaustion that the
@@ -6,6 +6,7 @@
 #include "pt_device.h"
 #include "pt_internal.h"
 #include "pt_kernel.h"
+#include "../../include/ptcore_lab.h"
 
 #pragma clang fp contract(off)
 
@@ -53,43 +54,11 @@ __global__ void __launch_bounds__(256) unary_compare_kernel(int fn_a, int fn_b, 
 
 }  // namespace pt
 
-namespace pt {
-// denoise_kernel: src/denoise.cu:9-29.  One lane per pixel, lanes along columns (the reference maps
-// adjacent threads to adjacent rows); 12 B read + 12 B written per pixel: HBM-bound and tiny.
-__global__ void __launch_bounds__(256) display_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int width,
-                                                           uint32_t pixels) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= pixels) return;
-  const uint32_t row = i / (uint32_t)width, col = i % (uint32_t)width;
-  const float* px = in + (size_t)i * 14;
-  uint32_t packed = 1u << 24;  // uchar4 {r, g, b, 1}, little endian
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float v = fminf(fmaxf(px[k], 0.0f), 1.0f);              // :18-20
-    packed |= (uint32_t)(unsigned char)((double)v * 255.0) << (8 * k);  // :23
-  }
-  float* o = out + (size_t)i * 3;
-  o[0] = (float)col;                     // :26
-  o[1] = (float)(width - (int)row);      // :27
-  o[2] = __uint_as_float(packed);        // :28
-}
-}  // namespace pt
-
 #define PT_HIPD(call)                                                                             \
   do {                                                                                            \
     hipError_t e_ = (call);                                                                       \
     if (e_ != hipSuccess) return pt_fail(PT_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
-
-extern "C" int pt_display_pack(const float* d_buffer, int width, int height, float* d_vertices, void* hip_stream) {
-  if (width <= 0 || height <= 0 || !d_buffer || !d_vertices) return pt_fail(PT_EINVAL, "pt_display_pack: bad arguments");
-  const uint64_t pixels = (uint64_t)width * (uint64_t)height;
-  if (pixels > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_display_pack: image too large");
-  hipLaunchKernelGGL(pt::display_pack_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-                     d_buffer, d_vertices, width, (uint32_t)pixels);
-  PT_HIPD(hipGetLastError());
-  return PT_OK;
-}
 
 extern "C" int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n) {
   if (fn < 0 || fn >= PT_FN_COUNT || (n && (!d_in || !d_out))) return pt_fail(PT_EINVAL, "pt_debug_unary_map: bad arguments");
@@ -116,5 +85,17 @@ extern "C" int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, u
   if (e != hipSuccess) return pt_fail(PT_EHIP, "pt_debug_unary_compare: %s", hipGetErrorString(e));
   *n_mismatch = h[0];
   if (example_bits) *example_bits = (uint32_t)h[1];
+  return PT_OK;
+}
+
+// diagnostics: build variant 11's grid for a scene and return its 16-word header
+extern "C" int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]) {
+  if (!d_spheres || !header_out || n_spheres < 1) return pt_fail(PT_EINVAL, "pt_debug_grid_header: bad arguments");
+  uint32_t* d = nullptr;
+  PT_HIPD(hipMalloc((void**)&d, pt_kernel_accel_bytes()));
+  hipError_t e = pt_launch_build_grid(d_spheres, n_spheres, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(header_out, d, 64, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PT_HIPD(e);
   return PT_OK;
 }

@@ -126,12 +126,18 @@ extern "C" int pt_scene_random(int n, uint64_t seed, int with_walls, pt_sphere* 
 
 extern "C" int pt_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int width, int height,
                                float basis_out[12]) {
-  if (!pos || !basis_out || width <= 0 || height <= 0) return pt_fail(PT_EINVAL, "pt_camera_basis: bad arguments");
+  const float world_up[3] = {0.0f, 1.0f, 0.0f};  // Camera.h:58
+  return pt_camera_basis_up(pos, yaw_deg, pitch_deg, world_up, width, height, basis_out);
+}
+
+extern "C" int pt_camera_basis_up(const float pos[3], float yaw_deg, float pitch_deg, const float world_up[3], int width,
+                                  int height, float basis_out[12]) {
+  if (!pos || !world_up || !basis_out || width <= 0 || height <= 0) return pt_fail(PT_EINVAL, "pt_camera_basis: bad arguments");
   const float rad = 0.01745329251994329576923690768489f;  // glm::radians
   // Camera::updateCameraVectors, include/Camera.h:153-164
   const float yaw = yaw_deg * rad, pitch = pitch_deg * rad;
   const V3 front = normalize(V3{std::cos(yaw) * std::cos(pitch), std::sin(pitch), std::sin(yaw) * std::cos(pitch)});
-  const V3 right = normalize(cross(front, V3{0.0f, 1.0f, 0.0f}));
+  const V3 right = normalize(cross(front, V3{world_up[0], world_up[1], world_up[2]}));
   const V3 up = normalize(cross(right, front));
   const V3 eye{pos[0], pos[1], pos[2]};
   // Camera::GetViewMatrix -> glm::lookAt (right-handed), include/Camera.h:73-76

@@ -66,7 +66,11 @@ struct PixelKernelArgs {
   uint64_t seed;
 };
 
+#ifndef PT_BUILD_EXPERIMENTS
+#define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9 (libptcore_lab.so)
+#endif
 int pt_kernel_num_variants(void);
+bool pt_kernel_has_variant(int variant);  // compiled into this library?
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);

@@ -459,21 +459,32 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool 
   }
   switch (variant) {
     case 0: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 0> : pt::pixel_kernel<PT_RNG_XORWOW, 0>;
+#if PT_BUILD_EXPERIMENTS  // measured negative results and stepping stones: libptcore_lab.so only
     case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
     case 2: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 2> : pt::pixel_kernel<PT_RNG_XORWOW, 2>;
     case 3: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 3> : pt::pixel_kernel<PT_RNG_XORWOW, 3>;
     case 4: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 4> : pt::pixel_kernel<PT_RNG_XORWOW, 4>;
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
-    case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
     case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
-    case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4>;
     case 9: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2>;
+#endif
+    case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
+    case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4>;
     case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10> : pt::pixel_kernel<PT_RNG_XORWOW, 10>;
     default: return nullptr;
   }
 }
 
 int pt_kernel_num_variants(void) { return 12; }
+
+bool pt_kernel_has_variant(int variant) {
+  if (variant < 0 || variant >= 12) return false;
+#if PT_BUILD_EXPERIMENTS
+  return true;
+#else
+  return variant == 0 || variant == 6 || variant == 8 || variant == 10 || variant == 11;
+#endif
+}
 
 size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 

@@ -152,7 +152,7 @@ int main(int argc, const char** argv) {
     single = new Renderer(width, height, samplesPerPixel, threadsPerBlock, opts);
   }
   auto render = [&](OutputBuffer b, const Scene& s, const Camera& c) { return tiled ? tiled->Render(b, s, c) : single->Render(b, s, c); };
-  Camera camera(cameraPos[0], cameraPos[1], cameraPos[2], cameraView[0], cameraView[1]);
+  Camera camera(glm::vec3(cameraPos[0], cameraPos[1], cameraPos[2]), cameraView[0], cameraView[1]);  // main.cu:128 verbatim
 
   // allocate output buffer (main.cu:131-139)
   OutputBuffer d_buffer(width, height);
@@ -174,7 +174,7 @@ int main(int argc, const char** argv) {
       std::istringstream ls(line);
       float x, y, z, yaw, pitch;
       if (!(ls >> x >> y >> z >> yaw >> pitch)) continue;
-      Camera pose(x, y, z, yaw, pitch);
+      Camera pose(glm::vec3(x, y, z), yaw, pitch);
       renderTime = render(d_buffer, scene, pose);
       times.push_back(renderTime);
     }

@@ -74,7 +74,7 @@ typedef struct pt_renderer_opts {
                         /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
   int32_t variant;      /* kernel variant, all produce identical bits: -1 (default) = automatic    */
                         /*   (by scene size, tile size and generator), 0 = literal transcription,  */
-                        /*   1..11 see DESIGN.md section 4                                         */
+                        /*   6, 8, 10, 11 see DESIGN.md section 4 (1-5, 7, 9: libptcore_lab.so)    */
   int32_t layout;       /* PT_LAYOUT_INTERLEAVED (default): the reference's [row][col][14] buffer  */
                         /*   (pathtrace.cu:240-254); PT_LAYOUT_PLANAR: [14][rows][width] of this   */
                         /*   renderer's tile -- same values, channel-first like a torch NCHW tensor */
@@ -227,29 +227,10 @@ int pt_scene_random(int n, uint64_t seed, int with_walls, pt_sphere* out);
  * restated without glm (float32, same operation order as glm 0.9.8). */
 int pt_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int width, int height,
                     float basis_out[12]);
-
-/* ---- diagnostics (tests only; no reference counterpart) ------------------------------------ */
-/* Scalar building blocks of the device code, evaluated elementwise on the GPU. */
-enum {
-  PT_FN_INV_SQRT_LITERAL = 0, /* 1.0f / sqrtf(x): helper_math normalize's rsqrtf (contract C2) */
-  PT_FN_INV_SQRT_FAST = 1,    /* the 7-instruction sequence the kernel uses for the same value   */
-  PT_FN_SQRT_LITERAL = 2,     /* sqrtf(x)                                                        */
-  PT_FN_SQRT_FAST = 3,        /* 5-instruction correctly rounded sqrt                             */
-  PT_FN_SIN = 4,              /* contract C4 sin on (0, 2*pi]                                     */
-  PT_FN_COS = 5,              /* contract C4 cos                                                  */
-  PT_FN_UNIFORM = 6,          /* curand_uniform mapping of the argument's BIT PATTERN             */
-  PT_FN_ONEMINUS_LITERAL = 7, /* (float)sqrt(1.0 - (double)(x*x)), pathtrace.cu:134               */
-  PT_FN_ONEMINUS_FAST = 8,    /* same through the lean correctly rounded double sqrt              */
-  PT_FN_COUNT = 9
-};
-int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
-/* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits
- * (count <= 2^32); NaN results compare equal.  *n_mismatch = number of differing inputs. */
-int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
-                           uint32_t* example_bits);
-/* Diagnostics: builds the uniform grid of kernel variant 11 for a scene and returns its 64-byte header
- * {valid, nx, ny, nz, origin xyz, cell size, 1/cell size, slack, centre xyz, (2E)^2, n_big, n_items}. */
-int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]);
+/* Same with an explicit WorldUp: the scalar constructor Camera(posX, posY, posZ, upX, upY, upZ, yaw, pitch),
+ * include/Camera.h:63-70 (pt_camera_basis uses the (0, 1, 0) of the vector constructor, Camera.h:58). */
+int pt_camera_basis_up(const float pos[3], float yaw_deg, float pitch_deg, const float world_up[3],
+                       int width, int height, float basis_out[12]);
 
 #ifdef __cplusplus
 }

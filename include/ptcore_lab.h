@@ -1,0 +1,42 @@
+/*
+ * ptcore_lab.h -- additional exports of libptcore_lab.so, the LAB build of the same sources
+ * (csrc/Makefile, -DPT_BUILD_EXPERIMENTS=1): everything in ptcore.h, plus the experimental kernel
+ * variants 1-5, 7 and 9 (stepping stones and measured negative results) and the
+ * diagnostic entry points below.  Loaded by the variant / exhaustive tests and the tools; the
+ * product library libptcore.so exports none of this.  No reference counterpart.
+ */
+#ifndef PTCORE_LAB_H
+#define PTCORE_LAB_H
+
+#include "ptcore.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scalar building blocks of the device code, evaluated elementwise on the GPU. */
+enum {
+  PT_FN_INV_SQRT_LITERAL = 0, /* 1.0f / sqrtf(x): helper_math normalize's rsqrtf (contract C2) */
+  PT_FN_INV_SQRT_FAST = 1,    /* the 7-instruction sequence the kernel uses for the same value   */
+  PT_FN_SQRT_LITERAL = 2,     /* sqrtf(x)                                                        */
+  PT_FN_SQRT_FAST = 3,        /* 5-instruction correctly rounded sqrt                             */
+  PT_FN_SIN = 4,              /* contract C4 sin on (0, 2*pi]                                     */
+  PT_FN_COS = 5,              /* contract C4 cos                                                  */
+  PT_FN_UNIFORM = 6,          /* curand_uniform mapping of the argument's BIT PATTERN             */
+  PT_FN_ONEMINUS_LITERAL = 7, /* (float)sqrt(1.0 - (double)(x*x)), pathtrace.cu:134               */
+  PT_FN_ONEMINUS_FAST = 8,    /* same through the lean correctly rounded double sqrt              */
+  PT_FN_COUNT = 9
+};
+int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
+/* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits
+ * (count <= 2^32); NaN results compare equal.  *n_mismatch = number of differing inputs. */
+int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
+                           uint32_t* example_bits);
+/* Diagnostics: builds the uniform grid of kernel variant 11 for a scene and returns its 64-byte header
+ * {valid, nx, ny, nz, origin xyz, cell size, 1/cell size, slack, centre xyz, (2E)^2, n_big, n_items}. */
+int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_LAB_H */

@@ -98,6 +98,8 @@ def _bind(L):
     L.pto_scene_cornell.argtypes = [ctypes.c_void_p]
     L.pto_camera_basis.restype = None
     L.pto_camera_basis.argtypes = [fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, fp]
+    L.pto_camera_basis_up.restype = None
+    L.pto_camera_basis_up.argtypes = [fp, ctypes.c_float, ctypes.c_float, fp, ctypes.c_int, ctypes.c_int, fp]
     L.pto_display_pack.restype = None
     L.pto_display_pack.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
     L.pto_xorwow_init.restype = None
@@ -129,10 +131,14 @@ def scene_cornell():
     return s
 
 
-def camera_basis(pos=(50.0, 52.0, 295.6), yaw=-90.0, pitch=0.0, w=256, h=256):
+def camera_basis(pos=(50.0, 52.0, 295.6), yaw=-90.0, pitch=0.0, w=256, h=256, world_up=None):
     p = np.asarray(pos, dtype=np.float32)
     out = np.zeros(12, dtype=np.float32)
-    lib().pto_camera_basis(_fp(p), yaw, pitch, w, h, _fp(out))
+    if world_up is None:
+        lib().pto_camera_basis(_fp(p), yaw, pitch, w, h, _fp(out))
+    else:
+        u = np.asarray(world_up, dtype=np.float32)
+        lib().pto_camera_basis_up(_fp(p), yaw, pitch, _fp(u), w, h, _fp(out))
     return out
 
 

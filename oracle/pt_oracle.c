@@ -271,12 +271,19 @@ static m4 m4_inverse(const m4* a) {
 
 void pto_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int w, int h,
                       float basis_out[12]) {
+  const float up[3] = {0.0f, 1.0f, 0.0f}; /* Camera.h:58 */
+  pto_camera_basis_up(pos, yaw_deg, pitch_deg, up, w, h, basis_out);
+}
+
+/* WorldUp explicit: the scalar constructor, Camera.h:63-70 */
+void pto_camera_basis_up(const float pos[3], float yaw_deg, float pitch_deg, const float up_in[3], int w, int h,
+                         float basis_out[12]) {
   const float deg2rad = 0.01745329251994329576923690768489f;
   /* Camera.h:153-164 updateCameraVectors */
   float yaw = yaw_deg * deg2rad, pitch = pitch_deg * deg2rad;
   v3 front = mk3(cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch));
   front = normalize3(front);
-  v3 world_up = mk3(0.0f, 1.0f, 0.0f);
+  v3 world_up = mk3(up_in[0], up_in[1], up_in[2]);
   v3 right = normalize3(cross3(front, world_up));
   v3 up = normalize3(cross3(right, front));
   v3 eye = mk3(pos[0], pos[1], pos[2]);

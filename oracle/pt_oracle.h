@@ -77,6 +77,8 @@ void pto_scene_cornell(pto_sphere out[9]);
 /* Camera::updateCameraVectors + getEyeRayBasis (include/Camera.h:125-149,153-164). */
 void pto_camera_basis(const float pos[3], float yaw_deg, float pitch_deg, int w, int h,
                       float basis_out[12]);
+void pto_camera_basis_up(const float pos[3], float yaw_deg, float pitch_deg, const float world_up[3], int w, int h,
+                         float basis_out[12]);
 
 /* denoise_kernel (src/denoise.cu:9-29): clamp colour to [0,1], pack RGBA8 {r,g,b,1} into one float,
  * emit per pixel the vertex triple (col, width - row, packed).  in: [row][col][14], out: [row][col][3]. */

@@ -21,6 +21,14 @@ def pt():
 
 
 @pytest.fixture(scope="session")
+def lab():
+    """The same view bound to libptcore_lab.so: every experimental kernel variant + the pt_debug_* diagnostics."""
+    import __graft_entry__ as ge
+
+    return ge.load_lab()
+
+
+@pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (test infrastructure)."""
     import __graft_entry__ as ge
@@ -35,6 +43,9 @@ def gpu(pt):
     if pt.device_count() < 1:
         pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")
     pt.set_device(0)
+    import __graft_entry__ as ge
+
+    ge.load_lab().set_device(0)
     return pt.device_info()
 
 

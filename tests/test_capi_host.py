@@ -11,8 +11,8 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+def declared_symbols(header="ptcore.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,6 +25,20 @@ def test_library_exports_every_declared_symbol(pt):
     assert not missing, missing
     # and the ctypes table used by tests/bench covers the whole header
     assert sorted(pt.ABI) == names
+
+
+def test_product_library_is_lean_and_the_lab_library_is_a_superset(pt, lab):
+    """libptcore.so ships no diagnostics and no experimental kernels; libptcore_lab.so = the same ABI + include/ptcore_lab.h."""
+    import subprocess
+
+    prod = subprocess.run(["nm", "-D", "--defined-only", pt.LIB_PATH], capture_output=True, text=True).stdout
+    assert "pt_debug_" not in prod and not pt.IS_LAB
+    lab_names = declared_symbols("ptcore_lab.h")
+    assert lab_names == sorted(lab.LAB_ABI) and all(n.startswith("pt_debug_") for n in lab_names)
+    raw = ctypes.CDLL(lab.LIB_PATH)
+    assert lab.IS_LAB and not [n for n in declared_symbols() + lab_names if not hasattr(raw, n)]
+    assert lab.build_fingerprint() == pt.build_fingerprint() + "-lab"  # built from the same sources
+    assert os.path.getsize(pt.LIB_PATH) < os.path.getsize(lab.LIB_PATH)
 
 
 def test_abi_version_and_struct_layout(pt):
@@ -65,6 +79,20 @@ def test_camera_basis_matches_oracle_bitwise(pt, oracle, pose):
         a = pt.camera_basis(pos, yaw, pitch, w, h)
         b = oracle.camera_basis(pos, yaw, pitch, w, h)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_camera_basis_with_explicit_world_up(pt, oracle):
+    """The scalar Camera constructor's WorldUp (Camera.h:63-70): (0,1,0) is the vector constructor's basis; a tilted
+    or inverted up vector matches the oracle's restatement bit for bit and really changes the basis."""
+    pos = (50.0, 52.0, 295.6)
+    base = pt.camera_basis(pos, -90.0, 0.0, 512, 512)
+    assert np.array_equal(pt.camera_basis(pos, -90.0, 0.0, 512, 512, world_up=(0, 1, 0)).view(np.uint32), base.view(np.uint32))
+    for up in ((0.0, -1.0, 0.0), (0.3, 1.0, 0.1), (1.0, 0.0, 0.0)):
+        a = pt.camera_basis(pos, -75.0, 5.0, 640, 480, world_up=up)
+        b = oracle.camera_basis(pos, -75.0, 5.0, 640, 480, world_up=up)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), up
+    flipped = pt.camera_basis(pos, -90.0, 0.0, 512, 512, world_up=(0, -1, 0)).reshape(4, 3)
+    assert np.allclose(flipped[0], base.reshape(4, 3)[3], atol=1e-6)  # upside down: corner (-1,-1) <-> (+1,+1)
 
 
 def test_argument_validation(pt):
@@ -113,6 +141,33 @@ def test_mgpu_fails_loudly_without_gpu_and_validates_arguments(pt):
     mo = pt.MgpuOpts()
     pt.lib.pt_mgpu_opts_default(ctypes.byref(mo))
     assert (mo.gather, mo.timeout_ms) == (pt.GATHER_AUTO, 60000)
+
+
+def test_reference_construction_sequence_compiles_against_the_look_alikes(pt, tmp_path):
+    """src/main.cu:125-131,182-183 verbatim -- Camera(glm::vec3(...), yaw, pitch) included -- builds with plain g++
+    against cuda-pathtrace_amd/host/*.h; without a GPU it stops at the first device call with the GPUassert line."""
+    import subprocess
+
+    exe = str(tmp_path / "main_cu_lines")
+    libdir = os.path.join(ROOT, "cuda-pathtrace_amd")
+    res = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", ROOT, "-include", "iostream", "-o", exe,
+                          os.path.join(ROOT, "tests", "cpp", "main_cu_camera_line.cpp"), "-L", libdir, "-lptcore",
+                          "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True)
+    try:
+        have_gpu = pt.device_count() > 0
+    except pt.PtError:
+        have_gpu = False
+    if have_gpu:
+        assert run.returncode == 0 and "Render completed in" in run.stdout
+    else:
+        assert run.returncode != 0 and "GPUassert:" in run.stderr
+
+
+@pytest.mark.gpu
+def test_reference_construction_sequence_runs_on_the_gpu(pt, gpu, tmp_path):
+    test_reference_construction_sequence_compiles_against_the_look_alikes(pt, tmp_path)
 
 
 def _build_abi_example(tmp_path):

@@ -54,27 +54,25 @@ def test_matches_committed_fixture(pt, gpu, name):
 
 
 # ---- every kernel variant computes the same bits ---------------------------------------------------
-def _num_variants(pt):
-    n = 0
-    while True:
-        try:
-            pt.Renderer(8, 8, 1, variant=n).destroy()
-            n += 1
-        except pt.PtError:
-            return n
+def _all_variants(pt, lab):
+    """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 10, 11) from libptcore.so,
+    the experimental ones (1-5, 7, 9) from libptcore_lab.so."""
+    prod = pt.variants()
+    assert prod == [0, 6, 8, 10, 11] and lab.variants() == list(range(12))
+    return [(pt, v) for v in prod] + [(lab, v) for v in lab.variants() if v not in prod]
 
 
 @pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
 @pytest.mark.parametrize("spp", [1, 5, 8])
-def test_all_variants_bit_exact_vs_oracle(pt, oracle, gpu, rng, spp):
+def test_all_variants_bit_exact_vs_oracle(pt, lab, oracle, gpu, rng, spp):
     """Every kernel variant, even / odd / single sample counts (variant 7 pairs samples), on the
     closed box and on an open scene where paths escape at different depths (variant 7 then has to
     retrace the second sample of a pair from the first one's true generator state)."""
     basis = pt.camera_basis(width=96, height=96)
     for name, sph in (("cornell", pt.scene_cornell()), ("open", pt.scene_cornell()[[0, 2, 4, 6, 7, 8]])):
         ref = oracle.render(96, 96, spp, spheres=sph, basis=basis, rng_mode=rng)
-        for v in range(_num_variants(pt)):
-            img, _ = pt.render_frame(96, 96, spp, spheres=sph, basis=basis, rng_mode=rng, variant=v)
+        for mod, v in _all_variants(pt, lab):
+            img, _ = mod.render_frame(96, 96, spp, spheres=sph, basis=basis, rng_mode=rng, variant=v)
             assert_bit_exact(img, ref, f"{name} variant {v} rng {rng} spp {spp}")
 
 
@@ -131,14 +129,14 @@ def test_philox_frames_are_keyed_not_stateful(pt, oracle, gpu):
 
 # ---- BASELINE.json configs 4 and 5 at oracle-sized inputs, edge cases ---------------------------------
 @pytest.mark.parametrize("with_walls", [True, False], ids=["closed", "open"])
-def test_thousand_sphere_scene(pt, oracle, gpu, with_walls):
+def test_thousand_sphere_scene(pt, lab, oracle, gpu, with_walls):
     """config 4 shape: 1000 random spheres (LDS staging / intersect-loop stress); the open
     variant makes most paths escape at different depths (divergent early exit)."""
     sph = pt.scene_random(1000, seed=3, with_walls=with_walls)
     size, spp = 48, 2
     basis = pt.camera_basis(width=size, height=size)
-    for v in range(_num_variants(pt)):
-        img, _ = pt.render_frame(size, size, spp, spheres=sph, basis=basis, variant=v)
+    for mod, v in _all_variants(pt, lab):
+        img, _ = mod.render_frame(size, size, spp, spheres=sph, basis=basis, variant=v)
         ref = oracle.render(size, size, spp, spheres=sph, basis=basis)
         assert_bit_exact(img, ref, f"1000 spheres walls={with_walls} variant {v}")
 
@@ -158,7 +156,7 @@ def test_interactive_shape_eight_bounces(pt, oracle, gpu):
     r.destroy()
 
 
-def test_edge_cases(pt, oracle, gpu):
+def test_edge_cases(pt, lab, oracle, gpu):
     basis = pt.camera_basis(width=40, height=24)
     # non-square, ragged last workgroup (40*24 = 960 pixels = 3.75 workgroups)
     img, _ = pt.render_frame(40, 24, 3, basis=basis)
@@ -185,13 +183,16 @@ def test_edge_cases(pt, oracle, gpu):
     # too many spheres for the LDS staging budget: loud error, not a silent fallback
     # (the automatic choice has no limit: many-sphere scenes are not staged at all, see the next test)
     big = pt.scene_random(2500, seed=1)
-    with pytest.raises(pt.PtError) as e:
-        pt.render_frame(8, 8, 1, spheres=big, basis=pt.camera_basis(width=8, height=8), variant=5)
+    with pytest.raises(lab.PtError) as e:  # only the experimental variants still stage large scenes into LDS
+        lab.render_frame(8, 8, 1, spheres=big, basis=pt.camera_basis(width=8, height=8), variant=5)
     assert e.value.code == -5
+    with pytest.raises(pt.PtError) as e:  # and the product library says so when asked for one of them
+        pt.Renderer(8, 8, 1, variant=5)
+    assert e.value.code == -1 and "libptcore_lab" in str(e.value)
 
 
 @pytest.mark.parametrize("rng", [0, 1])
-def test_planar_layout_is_the_transposed_frame(pt, oracle, gpu, rng):
+def test_planar_layout_is_the_transposed_frame(pt, lab, oracle, gpu, rng):
     """PT_LAYOUT_PLANAR writes [14][rows][width] (channel-first, coalesced without the LDS transpose); the values
     are the reference's, so the planes must equal the oracle's interleaved frame transposed -- every kernel
     family (one lane per pixel, four lanes per pixel, regeneration, grid), full frame and a row tile."""
@@ -200,7 +201,8 @@ def test_planar_layout_is_the_transposed_frame(pt, oracle, gpu, rng):
     for scene, variants in ((pt.scene_cornell(), (0, 6, 8, 9, None)), (pt.scene_random(300, seed=4), (6, 8, 10, 11, None))):
         ref = oracle.render(size, size, spp, spheres=scene, basis=basis, rng_mode=rng)
         for v in variants:
-            img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, rng_mode=rng, variant=v, layout=pt.LAYOUT_PLANAR)
+            mod = lab if v == 9 else pt
+            img, _ = mod.render_frame(size, size, spp, spheres=scene, basis=basis, rng_mode=rng, variant=v, layout=pt.LAYOUT_PLANAR)
             planes = img.reshape(14, size, size)
             assert_bit_exact(np.ascontiguousarray(planes.transpose(1, 2, 0)), ref, f"planar variant={v}")
     tile, _ = pt.render_frame(size, size, spp, basis=basis, rng_mode=rng, row_begin=17, row_end=50, layout=pt.LAYOUT_PLANAR)
@@ -211,7 +213,7 @@ def test_planar_layout_is_the_transposed_frame(pt, oracle, gpu, rng):
 
 
 @pytest.mark.parametrize("rng", [0, 1])
-def test_uniform_grid_variant(pt, oracle, gpu, rng):
+def test_uniform_grid_variant(pt, lab, oracle, gpu, rng):
     """Variant 11 changes which spheres a lane tests (conservative uniform grid, rebuilt on the device every
     frame), never the result: against the oracle on closed/open scenes, a far-away camera (rays not admitted
     to the grid), radii spanning two decades (grid refused: too many spheres that cannot be registered) and a
@@ -229,7 +231,7 @@ def test_uniform_grid_variant(pt, oracle, gpu, rng):
             for v in (11, None):
                 img, _ = pt.render_frame(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=v)
                 assert_bit_exact(img, ref, f"grid {name} eye={eye} variant={v}")
-    assert pt.grid_header(scenes["walls"])["valid"] == 1 and pt.grid_header(wide)["valid"] == 0
+    assert lab.grid_header(scenes["walls"])["valid"] == 1 and lab.grid_header(wide)["valid"] == 0
     r = pt.Renderer(size, size, 3, rng_mode=rng)
     assert r.kernel_info(400)["variant"] == 11
     # the grid belongs to the frame, not to the renderer: move the spheres between two frames
@@ -409,7 +411,7 @@ def _random_scene(rng, n):
 
 
 @pytest.mark.parametrize("seed", range(48))
-def test_fuzz_random_scenes_all_variants(pt, oracle, gpu, seed):
+def test_fuzz_random_scenes_all_variants(pt, lab, oracle, gpu, seed):
     """Random sphere soups (huge walls, nested and DUPLICATED spheres = exact ties, origins near
     surfaces), random cameras, both generators: every variant must equal the oracle bit for bit.
     Duplicated spheres force the first-index tie-break and the 'ambiguous -> literal loop' path."""
@@ -424,8 +426,8 @@ def test_fuzz_random_scenes_all_variants(pt, oracle, gpu, seed):
     mb = int(rng.integers(1, 9))
     ref = oracle.render(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb)
     assert np.isfinite(ref).all()
-    for v in range(_num_variants(pt)):
-        img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
+    for mod, v in _all_variants(pt, lab):
+        img, _ = mod.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
         assert_bit_exact(img, ref, f"fuzz seed {seed} n={n} spp={spp} bounces={mb} variant {v}")
 
 

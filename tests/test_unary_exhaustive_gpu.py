@@ -1,12 +1,19 @@
 """Device-side scalar building blocks: (1) the cheap correctly rounded sqrt / 1/sqrt sequences
 are compared with the literal expressions for ALL 2^32 float bit patterns (proof by
-exhaustion); (2) the device definitions are compared with the CPU on dense samples."""
+exhaustion); (2) the device definitions are compared with the CPU on dense samples.
+The pt_debug_* entry points live in the lab library only (include/ptcore_lab.h): `pt` below is that view.
+Same device code as the product build: both libraries compile the same pt_device.h."""
 import math
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def pt(lab):
+    return lab
 
 
 @pytest.mark.parametrize("fast,literal", [(1, 0), (3, 2)], ids=["inv_sqrt", "sqrt"])

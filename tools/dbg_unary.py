@@ -1,7 +1,7 @@
 import sys, numpy as np
 sys.path.insert(0,'.')
 import __graft_entry__ as ge
-pt=ge.load_package(); pt.set_device(0)
+pt=ge.load_lab(); pt.set_device(0)  # pt_debug_* live in the lab library
 print("sqrt fast vs literal:", pt.unary_compare(3,2,0,1<<32))
 print("inv fast vs literal:", pt.unary_compare(1,0,0,1<<32))
 # locate mismatches of inv by scanning exponent blocks

@@ -5,7 +5,7 @@ import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
-pt = ge.load_package(); pt.set_device(0)
+pt = ge.load_lab(); pt.set_device(0)  # grid_header is a lab-library diagnostic
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 size = 1024
 d_out = pt.DeviceBuffer(size * size * 56)

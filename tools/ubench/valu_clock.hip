@@ -1,45 +1,59 @@
-// valu_clock.hip -- separates CLOCK from CYCLES in the VALU issue-cost measurement (tools/ubench/valu_cost.hip
-// timed 0.3 ms kernels with events only, so "1.125 ns per v_add_f32 per SIMD" could be 2 cycles at 1.8 GHz or
-// 2.7 cycles at 2.4 GHz).  Here every wave reads s_memtime (shader clock ticks, MI355X_MICROARCH.md) and the
-// constant 100 MHz wall clock at its start and end, kernels run from 0.3 ms to > 50 ms (ITER is a run-time
-// argument), at 8 and at 4 waves per SIMD.  Output per instruction: ns / instr / SIMD from events, cycles /
-// instr / SIMD from s_memtime, and the clock the wave actually ran at = s_memtime ticks / wall-clock time.
+// valu_clock.hip -- what does one SIMD really issue per cycle?  (tools/ubench/valu_cost.hip timed 0.3 ms kernels with
+// events and ASSUMED that a grid of 8 blocks per CU puts exactly 8 waves on every SIMD: "1.125 ns per v_add_f32 per SIMD".)
+// Here every wave records: s_memtime ticks (shader clock) and the constant 100 MHz real-time counter at its start and
+// end, and WHERE it ran (HW_ID: SE / SH / CU / SIMD, XCC_ID).  The host groups the waves by SIMD, so the number of waves
+// that really shared a SIMD is known instead of assumed, and reports per instruction:
+//   - how the dispatcher distributed the waves (histogram of waves per SIMD),
+//   - cycles per instruction per SIMD = (a wave's ticks / its instructions) / (waves on its SIMD), over SIMDs whose waves
+//     all ran concurrently, for each occupancy that occurred,
+//   - the clock the waves ran at (ticks per real-time ns), and the event-timed kernel duration for comparison.
+// Kernels run > 50 ms (ITER is a run-time argument).
 // Build: hipcc --offload-arch=gfx950 -O2 -o valu_clock valu_clock.hip ; run: ./valu_clock
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <map>
+#include <vector>
+
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-struct Stamp { unsigned long long cyc, wall; };
+struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
+
+#define PROLOGUE                                                                                         \
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
+#define EPILOGUE                                                                                         \
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();                     \
+    if ((threadIdx.x & 63) == 0)                                                                         \
+      st[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] =                                          \
+          Stamp{c1 - c0, w0, w1, (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)), (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11))};
 
 #define KERNEL32(NAME, ASM)                                                                              \
   __global__ void __launch_bounds__(256) k_##NAME(float* out, Stamp* st, float seed, int iters) {        \
     float r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3, r4 = seed + 4, r5 = seed + 5, r6 = seed + 6, \
           r7 = seed + 7, x = seed * 0.5f + 1.0f, y = 1.0001f;                                             \
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();                     \
+    PROLOGUE                                                                                             \
     for (int i = 0; i < iters; i++) {                                                                    \
       asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                               \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
                    : "v"(x), "v"(y));                                                                    \
     }                                                                                                    \
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();                     \
+    EPILOGUE                                                                                             \
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                         \
-    if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, w1 - w0};      \
   }
 #define KERNEL64(NAME, ASM)                                                                              \
   __global__ void __launch_bounds__(256) k_##NAME(float* out, Stamp* st, float seed, int iters) {        \
     double r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3, r4 = seed + 4, r5 = seed + 5, r6 = seed + 6, \
            r7 = seed + 7, x = seed * 0.5 + 1.0, y = 1.0001;                                               \
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();                     \
+    PROLOGUE                                                                                             \
     for (int i = 0; i < iters; i++) {                                                                    \
       asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                               \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
                    : "v"(x), "v"(y));                                                                    \
     }                                                                                                    \
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();                     \
+    EPILOGUE                                                                                             \
     out[blockIdx.x * 256 + threadIdx.x] = (float)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);                 \
-    if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, w1 - w0};      \
   }
 
 #define A_ADD32(n) "v_add_f32 %" #n ", %" #n ", %8\n"
@@ -69,47 +83,75 @@ typedef void (*kfn)(float*, Stamp*, float, int);
 struct Entry { const char* name; kfn fn; int per_group; };  // instructions per ASM group
 #define E(n, k) {#n, k_##n, k}
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
+  const int iters = argc > 1 ? atoi(argv[1]) : 524288;
   float* out;
   Stamp* st;
   const int max_blocks = cus * 8;
   CHECK(hipMalloc(&out, (size_t)max_blocks * 256 * sizeof(float)));
   CHECK(hipMalloc(&st, (size_t)max_blocks * 4 * sizeof(Stamp)));
-  Stamp* hst = (Stamp*)malloc((size_t)max_blocks * 4 * sizeof(Stamp));
+  std::vector<Stamp> hst((size_t)max_blocks * 4);
   Entry es[] = {E(add_f32, 1), E(mul_f32, 1), E(fma_f32, 1), E(min_f32, 1), E(mov_b32, 1), E(xor_b32, 1), E(rcp_f32, 1),
                 E(cmp_cnd_pair, 2), E(add_f64, 1), E(fma_f64, 1), E(rcp_f64, 1)};
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
-  printf("%s, %d CUs, clockRate %d kHz\n", prop.name, cus, prop.clockRate);
-  printf("%-14s %5s %9s %9s %13s %13s %9s\n", "instruction", "w/SIMD", "iters", "ms", "ns/instr/SIMD", "cyc/instr/SIMD", "clock GHz");
-  const int iters_list[] = {4096, 65536, 786432};
+  printf("%s, %d CUs, clockRate %d kHz, %d iterations x 8 instructions per wave\n", prop.name, cus, prop.clockRate, iters);
   for (auto& e : es) {
-    for (int wps = 8; wps >= 4; wps -= 4) {
-      const int nb = cus * wps;  // wps blocks of 4 waves per CU = wps waves per SIMD, all resident at once
-      for (int iters : iters_list) {
-        if (wps == 4 && iters != 65536) continue;
-        hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, iters > 65536 ? 65536 : iters);  // warm
-        CHECK(hipDeviceSynchronize());
-        CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, iters);
-        CHECK(hipEventRecord(b));
-        CHECK(hipEventSynchronize(b));
-        float ms;
-        CHECK(hipEventElapsedTime(&ms, a, b));
-        CHECK(hipMemcpy(hst, st, (size_t)nb * 4 * sizeof(Stamp), hipMemcpyDeviceToHost));
-        double cyc = 0, wall = 0;
-        for (int i = 0; i < nb * 4; i++) { cyc += (double)hst[i].cyc; wall += (double)hst[i].wall; }
-        cyc /= nb * 4; wall /= nb * 4;  // mean per wave
-        const double instr_wave = (double)iters * 8 * e.per_group;
-        const double ns = ms * 1e6 / (instr_wave * wps);
-        const double cpi = cyc / (instr_wave * wps);
-        const double ghz = cyc / (wall * 10.0);  // wall clock ticks at 100 MHz = 10 ns
-        printf("%-14s %5d %9d %9.3f %13.3f %13.3f %9.3f\n", e.name, wps, iters, ms, ns, cpi, ghz);
+    for (int wps : {8, 4, 2}) {
+      const int nb = cus * wps;  // wps blocks of 4 waves per CU: wps waves per SIMD IF the dispatcher spreads them evenly
+      hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, 4096);  // warm
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(a));
+      hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, iters);
+      CHECK(hipEventRecord(b));
+      CHECK(hipEventSynchronize(b));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, a, b));
+      const int nw = nb * 4;
+      CHECK(hipMemcpy(hst.data(), st, (size_t)nw * sizeof(Stamp), hipMemcpyDeviceToHost));
+      // group by SIMD: xcc | se | sh | cu | simd
+      std::map<unsigned, std::vector<int>> simds;
+      unsigned long long t_first = ~0ull, t_last = 0;
+      for (int i = 0; i < nw; i++) {
+        const unsigned h = hst[i].hwid;
+        const unsigned key = ((hst[i].xcc & 15u) << 12) | (((h >> 13) & 7u) << 9) | (((h >> 12) & 1u) << 8) | (((h >> 8) & 15u) << 4) | ((h >> 4) & 3u);
+        simds[key].push_back(i);
+        t_first = std::min(t_first, hst[i].w0);
+        t_last = std::max(t_last, hst[i].w1);
       }
+      const double instr_wave = (double)iters * 8 * e.per_group;
+      // per occupancy n: SIMDs whose n waves overlapped for >= 98 % of their lifetimes
+      std::map<int, int> hist;
+      std::map<int, std::pair<double, int>> cpi;  // n -> (sum of cycles/instr/SIMD, count)
+      double ghz_sum = 0;
+      for (auto& kv : simds) {
+        const auto& ws = kv.second;
+        const int n = (int)ws.size();
+        hist[n]++;
+        unsigned long long s_max = 0, e_min = ~0ull, s_min = ~0ull, e_max = 0;
+        double cyc = 0;
+        for (int i : ws) {
+          s_max = std::max(s_max, hst[i].w0); s_min = std::min(s_min, hst[i].w0);
+          e_min = std::min(e_min, hst[i].w1); e_max = std::max(e_max, hst[i].w1);
+          cyc += (double)hst[i].cyc;
+        }
+        const double overlap = e_min > s_max ? (double)(e_min - s_max) / (double)(e_max - s_min) : 0.0;
+        if (overlap >= 0.98) {
+          cpi[n].first += cyc / n / instr_wave / n;
+          cpi[n].second++;
+        }
+      }
+      for (int i = 0; i < nw; i++) ghz_sum += (double)hst[i].cyc / ((double)(hst[i].w1 - hst[i].w0) * 10.0);
+      printf("%-13s grid %4d blocks: event %8.3f ms, first start -> last end %8.3f ms, clock %.3f GHz, %zu SIMDs used; waves/SIMD histogram:",
+             e.name, nb, ms, (double)(t_last - t_first) * 1e-5, ghz_sum / nw, simds.size());
+      for (auto& h : hist) printf(" %dx%d", h.first, h.second);
+      printf("\n              cycles/instr/SIMD by occupancy (concurrent SIMDs only):");
+      for (auto& c : cpi) printf("  n=%d: %.3f (%d SIMDs)", c.first, c.second.first / c.second.second, c.second.second);
+      printf("\n");
     }
   }
   return 0;

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 
-pt = ge.load_package()
+pt = ge.load_lab()  # every variant, including the experimental ones
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
