@@ -53,9 +53,11 @@ class RendererOpts(ctypes.Structure):
         ("persist_rng", ctypes.c_int32),
         ("variant", ctypes.c_int32),
         ("layout", ctypes.c_int32),
+        ("fast_math", ctypes.c_int32),
     ]
 
 
+VARIANT_FAST = 100
 LAYOUT_INTERLEAVED, LAYOUT_PLANAR = 0, 1
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER_COPY = 0, 1, 2
 
@@ -310,13 +312,14 @@ class Renderer:
     """ctypes view of pt_renderer (the reference's class Renderer, include/Renderer.h)."""
 
     def __init__(self, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 row_begin=0, row_end=0, persist_rng=True, variant=None, layout=LAYOUT_INTERLEAVED):
+                 row_begin=0, row_end=0, persist_rng=True, variant=None, layout=LAYOUT_INTERLEAVED, fast_math=False):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
         o.row_begin, o.row_end = row_begin, row_end
         o.persist_rng = 1 if persist_rng else 0
         o.layout = layout
+        o.fast_math = 1 if fast_math else 0
         if variant is not None:
             o.variant = variant
         self.variant = o.variant
@@ -382,11 +385,12 @@ class MultiRenderer:
     device inside the library, RCCL or peer-copy exchange to devices[0])."""
 
     def __init__(self, devices, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 persist_rng=True, variant=None, gather=None, force_exchange=None, timeout_ms=None):
+                 persist_rng=True, variant=None, gather=None, force_exchange=None, timeout_ms=None, fast_math=False):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
         o.persist_rng = 1 if persist_rng else 0
+        o.fast_math = 1 if fast_math else 0
         if variant is not None:
             o.variant = variant
         mo = MgpuOpts()

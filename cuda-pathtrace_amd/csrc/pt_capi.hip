@@ -74,6 +74,7 @@ static int mark_last(pt_renderer* r, hipStream_t stream) {
 #define PT_SPLIT_MAX_WAVES_PER_SIMD 6
 
 static int effective_variant(pt_renderer* r, int n_spheres) {
+  if (r->opts.fast_math) return PT_VARIANT_FAST;
   if (!r->auto_variant) return r->opts.variant;
   if (r->fail_pending && hipEventQuery(r->ev_fail) == hipSuccess) {
     r->fail_pending = false;
@@ -165,6 +166,7 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
   o->persist_rng = 1;
   o->variant = PT_VARIANT_AUTO;
   o->layout = PT_LAYOUT_INTERLEAVED;
+  o->fast_math = 0;
 }
 
 static int setup_random(pt_renderer* r) {
@@ -193,6 +195,9 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.rng_mode != PT_RNG_XORWOW && o.rng_mode != PT_RNG_PHILOX)
     return pt_fail(PT_EINVAL, "pt_renderer_create: rng_mode %d", o.rng_mode);
   if (o.layout != PT_LAYOUT_INTERLEAVED && o.layout != PT_LAYOUT_PLANAR) return pt_fail(PT_EINVAL, "pt_renderer_create: layout %d", o.layout);
+  if (o.fast_math != 0 && o.fast_math != 1) return pt_fail(PT_EINVAL, "pt_renderer_create: fast_math %d", o.fast_math);
+  if (o.fast_math && o.variant != PT_VARIANT_AUTO)
+    return pt_fail(PT_EINVAL, "pt_renderer_create: fast_math has one kernel; leave variant at -1");
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
     return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11; "
                               "the experiments 1-5, 7, 9 live in libptcore_lab.so)", o.variant);
@@ -279,7 +284,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "render: bad scene (%d spheres)", n_spheres);
   if (!basis || !eye) return pt_fail(PT_EINVAL, "render: basis/eye is NULL");
   const int variant = effective_variant(r, n_spheres);
-  if (n_spheres > pt_kernel_max_spheres(variant))
+  if (variant != PT_VARIANT_FAST && n_spheres > pt_kernel_max_spheres(variant))
     return pt_fail(PT_ELIMIT, "render: %d spheres exceed the LDS staging limit of %d", n_spheres,
                    pt_kernel_max_spheres(variant));
   a->fail_count = r->d_fail;
@@ -307,6 +312,11 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
 // With the automatic policy a speculative launch is bracketed by the reset and the asynchronous
 // read-back of its failure counter (consulted by a later effective_variant()).  The bracket sits
 // OUTSIDE the event pair of pt_renderer_render so the returned kernel time is not distorted.
+static hipError_t launch(pt_renderer* r, const PixelKernelArgs& a, hipStream_t stream) {
+  if (r->launch_variant == PT_VARIANT_FAST) return pt_launch_fast_kernel(a, r->opts.rng_mode, stream);
+  return pt_launch_pixel_kernel(a, r->opts.rng_mode, r->launch_variant, stream);
+}
+
 static int watch_begin(pt_renderer* r, hipStream_t stream, bool* watching) {
   *watching = r->auto_variant && r->launch_variant == 8 && !r->fail_pending;
   if (*watching) PT_HIP(hipMemsetAsync(r->d_fail, 0, sizeof(uint32_t), stream));
@@ -332,7 +342,7 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
   bool watching = false;
   rc = watch_begin(r, (hipStream_t)hip_stream, &watching);
   if (rc != PT_OK) return rc;
-  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->launch_variant, (hipStream_t)hip_stream));
+  PT_HIP(launch(r, a, (hipStream_t)hip_stream));
   rc = watch_end(r, (hipStream_t)hip_stream, watching);
   if (rc != PT_OK) return rc;
   rc = mark_last(r, (hipStream_t)hip_stream);
@@ -354,7 +364,7 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   rc = watch_begin(r, nullptr, &watching);
   if (rc != PT_OK) return rc;
   PT_HIP(hipEventRecord(r->ev_start, nullptr));  // Renderer.h:68
-  PT_HIP(pt_launch_pixel_kernel(a, r->opts.rng_mode, r->launch_variant, nullptr));
+  PT_HIP(launch(r, a, nullptr));
   PT_HIP(hipEventRecord(r->ev_stop, nullptr));   // Renderer.h:70
   rc = watch_end(r, nullptr, watching);
   if (rc != PT_OK) return rc;
@@ -399,17 +409,20 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   if (!r || !info) return pt_fail(PT_EINVAL, "pt_renderer_kernel_info: NULL argument");
   hipFuncAttributes fa;
   const int variant = effective_variant(r, n_spheres);
-  PT_HIP(hipFuncGetAttributes(&fa, pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR)));
+  const bool fast = variant == PT_VARIANT_FAST;
+  PT_HIP(hipFuncGetAttributes(&fa, fast ? pt_fast_kernel_symbol(r->opts.rng_mode, n_spheres, r->opts.max_bounces)
+                                        : pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces,
+                                                           r->opts.layout == PT_LAYOUT_PLANAR)));
   info->block_threads = PT_BLOCK_THREADS;
   info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-  info->lds_bytes = (int)pt_kernel_lds_bytes(n_spheres, variant);
+  info->lds_bytes = (int)(fast ? pt_fast_kernel_lds_bytes(n_spheres) : pt_kernel_lds_bytes(n_spheres, variant));
   info->variant = variant;
   if (variant == 8 || variant == 9)
     info->grid_blocks = (int)(((uint64_t)r->tile_pixels * (variant == 8 ? 4 : 2) + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;
-  info->max_spheres = pt_kernel_max_spheres(variant);
+  info->max_spheres = fast ? (1 << 26) : pt_kernel_max_spheres(variant);
   return PT_OK;
 }
 

@@ -69,6 +69,8 @@ struct PixelKernelArgs {
 #ifndef PT_BUILD_EXPERIMENTS
 #define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9 (libptcore_lab.so)
 #endif
+#define PT_VARIANT_FAST 100     // reported by pt_renderer_kernel_info for a fast_math renderer (pt_fast.hip)
+#define PT_FAST_LDS_SPHERES 64  // the fast kernel stages scenes up to this size into LDS, larger ones are read in place
 int pt_kernel_num_variants(void);
 bool pt_kernel_has_variant(int variant);  // compiled into this library?
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs
@@ -79,3 +81,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);
+// toleranced fast mode (pt_fast.hip)
+const void* pt_fast_kernel_symbol(int rng_mode, int n_spheres, int max_bounces);
+size_t pt_fast_kernel_lds_bytes(int n_spheres);
+hipError_t pt_launch_fast_kernel(const PixelKernelArgs& a, int rng_mode, hipStream_t stream);

@@ -78,6 +78,10 @@ typedef struct pt_renderer_opts {
   int32_t layout;       /* PT_LAYOUT_INTERLEAVED (default): the reference's [row][col][14] buffer  */
                         /*   (pathtrace.cu:240-254); PT_LAYOUT_PLANAR: [14][rows][width] of this   */
                         /*   renderer's tile -- same values, channel-first like a torch NCHW tensor */
+  int32_t fast_math;    /* 0 (default): the bit-exact kernels.  1: the TOLERANCED fast mode -- same algorithm and */
+                        /*   generator streams, FMA contraction allowed (nvcc's default for the reference), FP32-only   */
+                        /*   cancellation-free intersectSphere, hardware rsq/sin/cos.  Results agree with the exact   */
+                        /*   kernels statistically, not bitwise (tolerances: tests/test_fast_mode_gpu.py).           */
 } pt_renderer_opts;
 
 typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */

@@ -1,7 +1,7 @@
 """Device-side scalar building blocks: (1) the cheap correctly rounded sqrt / 1/sqrt sequences
 are compared with the literal expressions for ALL 2^32 float bit patterns (proof by
 exhaustion); (2) the device definitions are compared with the CPU on dense samples.
-The pt_debug_* entry points live in the lab library only (include/ptcore_lab.h): `pt` below is that view.
+The pt_debug_* entry points live in the lab library only (include/ptcore_lab.h): `lab` below is that view.
 Same device code as the product build: both libraries compile the same pt_device.h."""
 import math
 
@@ -11,52 +11,47 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def pt(lab):
-    return lab
-
-
 @pytest.mark.parametrize("fast,literal", [(1, 0), (3, 2)], ids=["inv_sqrt", "sqrt"])
-def test_fast_sequences_equal_literal_for_every_float(pt, gpu, fast, literal):
-    bad, example = pt.unary_compare(fast, literal, 0, 1 << 32)
+def test_fast_sequences_equal_literal_for_every_float(lab, gpu, fast, literal):
+    bad, example = lab.unary_compare(fast, literal, 0, 1 << 32)
     assert bad == 0, f"{bad} mismatching inputs, e.g. bits 0x{example:08x}"
 
 
-def test_oneminus_fast_equals_literal_on_all_elevations(pt, gpu):
+def test_oneminus_fast_equals_literal_on_all_elevations(lab, gpu):
     # argument is ry = sqrtf(u) in [0, 1]: every float in [0, 1] (bits 0 .. 0x3f800000)
-    bad, example = pt.unary_compare(pt.FN_ONEMINUS_FAST, pt.FN_ONEMINUS_LITERAL, 0, 0x3F800001)
+    bad, example = lab.unary_compare(lab.FN_ONEMINUS_FAST, lab.FN_ONEMINUS_LITERAL, 0, 0x3F800001)
     assert bad == 0, f"{bad} mismatches, e.g. 0x{example:08x}"
 
 
-def test_device_literals_match_cpu(pt, oracle, gpu):
+def test_device_literals_match_cpu(lab, oracle, gpu):
     rng = np.random.default_rng(5)
     bits = np.concatenate([rng.integers(0x00800000, 0x7F800000, 1 << 22, dtype=np.uint32),
                            np.arange(0x3F000000, 0x3F000000 + (1 << 20), dtype=np.uint32),
                            np.uint32([0x00800000, 0x7F7FFFFF, 0x3F800000, 0x3F7FFFFF, 0x3F800001])])
     x = bits.view(np.float32)
     with np.errstate(over="ignore"):
-        assert np.array_equal(pt.unary_map(pt.FN_SQRT_LITERAL, x).view(np.uint32), np.sqrt(x).view(np.uint32))
+        assert np.array_equal(lab.unary_map(lab.FN_SQRT_LITERAL, x).view(np.uint32), np.sqrt(x).view(np.uint32))
         inv = (np.float32(1.0) / np.sqrt(x)).astype(np.float32)
-        assert np.array_equal(pt.unary_map(pt.FN_INV_SQRT_LITERAL, x).view(np.uint32), inv.view(np.uint32))
-        assert np.array_equal(pt.unary_map(pt.FN_INV_SQRT_FAST, x).view(np.uint32), inv.view(np.uint32))
+        assert np.array_equal(lab.unary_map(lab.FN_INV_SQRT_LITERAL, x).view(np.uint32), inv.view(np.uint32))
+        assert np.array_equal(lab.unary_map(lab.FN_INV_SQRT_FAST, x).view(np.uint32), inv.view(np.uint32))
     u = rng.uniform(0, 1, 1 << 20).astype(np.float32)
     om = np.sqrt(1.0 - (u * u).astype(np.float64)).astype(np.float32)
-    assert np.array_equal(pt.unary_map(pt.FN_ONEMINUS_LITERAL, u).view(np.uint32), om.view(np.uint32))
+    assert np.array_equal(lab.unary_map(lab.FN_ONEMINUS_LITERAL, u).view(np.uint32), om.view(np.uint32))
 
 
-def test_device_sincos_and_uniform_equal_oracle(pt, oracle, gpu):
+def test_device_sincos_and_uniform_equal_oracle(lab, oracle, gpu):
     import ctypes
 
     rng = np.random.default_rng(6)
     u32 = np.concatenate([rng.integers(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32),
                           np.uint32([0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF])])
-    uni = pt.unary_map(pt.FN_UNIFORM, u32.view(np.float32))
+    uni = lab.unary_map(lab.FN_UNIFORM, u32.view(np.float32))
     L = oracle.lib()
     ref = np.float32([L.pto_uniform_from_u32(int(v)) for v in u32[:20000]])
     assert np.array_equal(uni[:20000].view(np.uint32), ref.view(np.uint32))
     assert uni.min() > 0 and uni.max() <= 1.0
     phi = (uni * np.float32(2.0)) * np.float32(3.141592654)  # pathtrace.cu:132
-    s_dev, c_dev = pt.unary_map(pt.FN_SIN, phi), pt.unary_map(pt.FN_COS, phi)
+    s_dev, c_dev = lab.unary_map(lab.FN_SIN, phi), lab.unary_map(lab.FN_COS, phi)
     s, c = ctypes.c_float(), ctypes.c_float()
     for k in range(0, 60000, 3):
         L.pto_sincos(ctypes.c_float(float(phi[k])), ctypes.byref(s), ctypes.byref(c))

@@ -29,13 +29,14 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
       st[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] =                                          \
           Stamp{c1 - c0, w0, w1, (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)), (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11))};
 
+#define GROUP(ASM) ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)
 #define KERNEL32(NAME, ASM)                                                                              \
   __global__ void __launch_bounds__(256) k_##NAME(float* out, Stamp* st, float seed, int iters) {        \
     float r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3, r4 = seed + 4, r5 = seed + 5, r6 = seed + 6, \
           r7 = seed + 7, x = seed * 0.5f + 1.0f, y = 1.0001f;                                             \
     PROLOGUE                                                                                             \
     for (int i = 0; i < iters; i++) {                                                                    \
-      asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                               \
+      asm volatile(GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM)  \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
                    : "v"(x), "v"(y));                                                                    \
     }                                                                                                    \
@@ -48,7 +49,7 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
            r7 = seed + 7, x = seed * 0.5 + 1.0, y = 1.0001;                                               \
     PROLOGUE                                                                                             \
     for (int i = 0; i < iters; i++) {                                                                    \
-      asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                               \
+      asm volatile(GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM)  \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
                    : "v"(x), "v"(y));                                                                    \
     }                                                                                                    \
@@ -87,7 +88,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const int iters = argc > 1 ? atoi(argv[1]) : 524288;
+  const int iters = argc > 1 ? atoi(argv[1]) : 65536;  // x 64 instructions
   float* out;
   Stamp* st;
   const int max_blocks = cus * 8;
@@ -99,9 +100,9 @@ int main(int argc, char** argv) {
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
-  printf("%s, %d CUs, clockRate %d kHz, %d iterations x 8 instructions per wave\n", prop.name, cus, prop.clockRate, iters);
+  printf("%s, %d CUs, clockRate %d kHz, %d iterations x 64 instructions per wave\n", prop.name, cus, prop.clockRate, iters);
   for (auto& e : es) {
-    for (int wps : {8, 4, 2}) {
+    for (int wps : {8, 5, 4, 2, 1}) {
       const int nb = cus * wps;  // wps blocks of 4 waves per CU: wps waves per SIMD IF the dispatcher spreads them evenly
       hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, 4096);  // warm
       CHECK(hipDeviceSynchronize());
@@ -123,34 +124,19 @@ int main(int argc, char** argv) {
         t_first = std::min(t_first, hst[i].w0);
         t_last = std::max(t_last, hst[i].w1);
       }
-      const double instr_wave = (double)iters * 8 * e.per_group;
-      // per occupancy n: SIMDs whose n waves overlapped for >= 98 % of their lifetimes
+      const double instr_wave = (double)iters * 64 * e.per_group;
       std::map<int, int> hist;
-      std::map<int, std::pair<double, int>> cpi;  // n -> (sum of cycles/instr/SIMD, count)
-      double ghz_sum = 0;
-      for (auto& kv : simds) {
-        const auto& ws = kv.second;
-        const int n = (int)ws.size();
-        hist[n]++;
-        unsigned long long s_max = 0, e_min = ~0ull, s_min = ~0ull, e_max = 0;
-        double cyc = 0;
-        for (int i : ws) {
-          s_max = std::max(s_max, hst[i].w0); s_min = std::min(s_min, hst[i].w0);
-          e_min = std::min(e_min, hst[i].w1); e_max = std::max(e_max, hst[i].w1);
-          cyc += (double)hst[i].cyc;
-        }
-        const double overlap = e_min > s_max ? (double)(e_min - s_max) / (double)(e_max - s_min) : 0.0;
-        if (overlap >= 0.98) {
-          cpi[n].first += cyc / n / instr_wave / n;
-          cpi[n].second++;
-        }
-      }
+      for (auto& kv : simds) hist[(int)kv.second.size()]++;
+      double cyc_sum = 0, ghz_sum = 0;
+      for (int i = 0; i < nw; i++) cyc_sum += (double)hst[i].cyc;
       for (int i = 0; i < nw; i++) ghz_sum += (double)hst[i].cyc / ((double)(hst[i].w1 - hst[i].w0) * 10.0);
-      printf("%-13s grid %4d blocks: event %8.3f ms, first start -> last end %8.3f ms, clock %.3f GHz, %zu SIMDs used; waves/SIMD histogram:",
-             e.name, nb, ms, (double)(t_last - t_first) * 1e-5, ghz_sum / nw, simds.size());
-      for (auto& h : hist) printf(" %dx%d", h.first, h.second);
-      printf("\n              cycles/instr/SIMD by occupancy (concurrent SIMDs only):");
-      for (auto& c : cpi) printf("  n=%d: %.3f (%d SIMDs)", c.first, c.second.first / c.second.second, c.second.second);
+      const bool even = hist.size() == 1 && hist.begin()->first == wps;
+      printf("%-13s %d waves/SIMD%s: event %8.3f ms = %6.3f ns/instr/SIMD; wave ticks -> %6.3f cycles/instr/SIMD at %.3f GHz (ticks per real-time ns)",
+             e.name, wps, even ? "" : " (UNEVEN)", ms, ms * 1e6 / (instr_wave * wps), cyc_sum / nw / instr_wave / wps, ghz_sum / nw);
+      if (!even) {
+        printf("; waves/SIMD histogram:");
+        for (auto& h : hist) printf(" %dx%d", h.first, h.second);
+      }
       printf("\n");
     }
   }
