@@ -3,7 +3,7 @@
 // Same algorithm as src/pathtrace.cu:150-257 and the same generator streams as the contract kernels, but NOT the
 // numeric contract: this translation unit allows FMA contraction (what nvcc does to the reference by default) and
 // replaces the expensive exactly-rounded pieces by what the hardware offers:
-//   * intersectSphere (pathtrace.cu:72-91) in FP32 only, in the cancellation-free form: h = dot(d, off),
+//   * intersectSphere (pathtrace.cu:72-91) in FP32 only, in the cancellation-free form: h = dot(d, off), c as the reference rounds it,
 //     disc = h*h - a*c, q = h + sign(h) sqrt(disc), roots {-q/a, -c/q} (their product is c/a) -- no FP64 sqrt/divide;
 //   * normalize = v * v_rsq_f32(dot(v,v)) (1 ulp) -- CUDA's own rsqrtf is an approximation as well;
 //   * sinf/cosf(2 pi u) = v_sin_f32(u) / v_cos_f32(u) (the instructions take revolutions: no range reduction);
@@ -24,7 +24,11 @@ namespace fast {
 
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ F3 unit(F3 v) {
+#ifdef PT_FAST_DBG_NORMALIZE
+  const float k = 1.0f / sqrtf(dot3(v, v));
+#else
   const float k = __builtin_amdgcn_rsqf(dot3(v, v));
+#endif
   return mk3(v.x * k, v.y * k, v.z * k);
 }
 __device__ __forceinline__ float lum(F3 c) { return fmaf(0.2126f, c.x, fmaf(0.7152f, c.y, 0.0722f * c.z)); }
@@ -44,7 +48,12 @@ __device__ __forceinline__ float var_value(const Var& w) { return w.n < 2.0f ? 0
 __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, const float4 g, float& disc) {
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
   const float h = dot3(d, off);                                                      // b / 2
-  const float c = fmaf(off.x, off.x, fmaf(off.y, off.y, fmaf(off.z, off.z, -g.w)));  // :76
+  // :76 in the reference's order: |off|^2 is rounded BEFORE r^2 is subtracted.  For the 1e5-radius wall spheres that
+  // rounding (ulp 1024 at 1e10) moves the hit point by ~1e-3 units, and the image depends on it measurably: the
+  // light is a 0.78-deep cap of a 600-radius sphere below the ceiling sphere, so its visible area follows the ceiling's
+  // t to that precision.  Folding -r^2 into the fma chain is MORE accurate and shifts the mean radiance by 0.15 %
+  // (9 standard errors at 512^2 x 1024 spp) away from the reference's arithmetic -- measured, tools/fast_bias.py.
+  const float c = (off.x * off.x + off.y * off.y + off.z * off.z) - g.w;
   disc = fmaf(h, h, -a * c);                                                         // det / 4
   const float s = __builtin_amdgcn_sqrtf(disc);                                      // NaN when there is no real root
   const float q = h + copysignf(s, h);
@@ -180,8 +189,18 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_fast(PixelKerne
       // getCosineWeightedNormal (:126-136) around the unit normal
       const F3 o1 = unit(ortho_vector(normal));
       const F3 o2 = cross(normal, o1);
+#ifdef PT_FAST_DBG_OM
+      const float ry = sqrtf(u_el), om = (float)sqrt(1.0 - (double)(ry * ry));
+#else
       const float ry = __builtin_amdgcn_sqrtf(u_el), om = __builtin_amdgcn_sqrtf(1.0f - u_el);
+#endif
+#ifdef PT_FAST_DBG_SINCOS
+      float sn0, cs0;
+      pt_sincos(u_az * 2.0f * 3.141592654f, sn0, cs0);
+      const float cs = cs0 * om, sn = sn0 * om;
+#else
       const float cs = __builtin_amdgcn_cosf(u_az) * om, sn = __builtin_amdgcn_sinf(u_az) * om;  // arguments in revolutions
+#endif
       d = unit(mk3(fmaf(o1.x, cs, fmaf(o2.x, sn, normal.x * ry)), fmaf(o1.y, cs, fmaf(o2.y, sn, normal.y * ry)),
                    fmaf(o1.z, cs, fmaf(o2.z, sn, normal.z * ry))));  // :180
       if (n == 0) {  // :187-195

@@ -192,23 +192,27 @@ struct ScreenState {
   bool unsure;
 };
 
+// Everything in the screen is kept at HALF scale -- h = dot(d, off) = b / 2, hh = h*h = bb / 4, a*c = 4ac / 4, ... --
+// which spares the doubling of b per sphere: scaling by powers of two is exact, so every quantity below is exactly a
+// quarter (half for the root estimates T = a*t) of the contract-scale value it stands for, and every decision
+// (signs, relative margins, ranking) is the same one.
 __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
                                               ScreenState& st) {
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-  const float b = 2.0f * dot(d, off);
+  const float h = dot(d, off);                     // b / 2
   const float c = dot(off, off) - g.w;
-  const float bb = b * b;
-  const float a4c = rc.a4 * c;
+  const float hh = h * h;                          // bb / 4
+  const float ac = rc.a * c;                       // 4ac / 4
   // The contract's det = RN(bb - RN(4a*c)) is used only through its sign.  dacc below rounds the exact
   // bb - 4a*c once; the two can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|, and such spheres are
   // flagged unsure (|dacc| > 2^-21 |4ac| is required), so det itself need not be formed.
-  const float dacc = fmaf(-rc.a4, c, bb);          // one rounding of the contract's exact discriminant bb - 4ac
+  const float dacc = fmaf(-rc.a, c, hh);           // one rounding of the contract's exact discriminant (bb - 4ac) / 4
   const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the sign bit of dacc rejects it below
-  const float q = b + copysignf(s, b);             // |b| + s with b's sign: no cancellation
-  const float e = fmaf(b, b, -bb);                 // b*b - bb exactly: the rounding error of the contract's bb
-  const float num = a4c + e;
-  const float TA = -q;                             // root -b - sign(b) s (x 2a)
-  const float TB = -num * __builtin_amdgcn_rcpf(q);  // root -b + sign(b) s = -(4ac + (b*b - bb)) / q (x 2a)
+  const float q = h + copysignf(s, h);             // |h| + s with h's sign: no cancellation
+  const float e = fmaf(h, h, -hh);                 // h*h - hh exactly: the rounding error of the contract's bb (/ 4)
+  const float num = ac + e;
+  const float TA = -q;                             // root -b - sign(b) s (x 2a), halved: a * t
+  const float TB = -num * __builtin_amdgcn_rcpf(q);  // root -b + sign(b) s = -(4ac + (b*b - bb)) / q (x 2a), halved
   // The reference returns tNear if it is positive, else tFar.  Origin inside the sphere (c < 0): the roots
   // have opposite signs, that is the larger one.  Outside (c > 0): same sign, the smaller one (if it is
   // negative so is the other and the candidate is rejected either way).  One median with +-inf does both;
@@ -218,8 +222,8 @@ __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d,
   const uint32_t w = __float_as_uint(dacc) | __float_as_uint(T);
   uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
   key = (key & ~imask) | (uint32_t)i;
-  const float m = fabsf(a4c) * 4.7683716e-07f;  // 2^-21 |4ac| >> the rounding errors of num (and of det vs dacc)
-  st.unsure = st.unsure | !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m);
+  const float m = fabsf(ac) * 4.7683716e-07f;  // 2^-21 |4ac| (/ 4) >> the rounding errors of num (and of det vs dacc)
+  st.unsure = st.unsure | !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(ac)) > m);
   st.k2 = umed3(st.k1, st.k2, key);
   st.k1 = st.k1 < key ? st.k1 : key;
 }
@@ -228,7 +232,7 @@ template <bool NB>
 __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                               float& t_hit, int& idx) {
   if (n <= 0) return false;
-  const float Tlim = 1000000.0f * (2.0f * rc.a);
+  const float Tlim = 1000000.0f * rc.a;  // the keys rank T = a*t (screen_sphere)
   const uint32_t lim_hi_bits = __float_as_uint(Tlim * 1.0000153f);
   const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));  // index bits (wave-uniform)
   const uint32_t imask = (1u << ib) - 1u;
@@ -475,7 +479,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   bool ambiguous[P];
 #pragma unroll
   for (int p = 0; p < P; p++) {
-    const float Tlim = 1000000.0f * (2.0f * rc[p].a);
+    const float Tlim = 1000000.0f * rc[p].a;  // the keys rank T = a*t (screen_sphere)
     const bool has = st[p].k1 < __float_as_uint(Tlim * 1.0000153f);
     const float T1 = __uint_as_float(st[p].k1 & ~imask);
     ambiguous[p] = st[p].unsure | (has & (((st[p].k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));

@@ -28,7 +28,7 @@ struct GridLds;  // pt_grid.h
 struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
   float4* mat0;  // {ex, ey, ez, colx}
-  float4* mat1;  // {coly, colz, 0, 0}
+  float4* mat1;  // {coly, colz, luminance(col), 0}: the albedo luminance of pathtrace.cu:193 is a per-sphere constant
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
@@ -68,7 +68,7 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
     const float rr = sp.radius * sp.radius;
     s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], rr);
     s.mat0[i] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], sp.color[0]);
-    s.mat1[i] = make_float4(sp.color[1], sp.color[2], 0.0f, 0.0f);
+    s.mat1[i] = make_float4(sp.color[1], sp.color[2], luminance(mk3(sp.color[0], sp.color[1], sp.color[2])), 0.0f);
     if constexpr (WITH_PAIR) {
       float* pa = reinterpret_cast<float*>(s.pair + 2 * (i >> 1)) + (i & 1);
       pa[0] = sp.pos[0];
@@ -88,16 +88,18 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
 }
 
 // emission and colour of sphere idx (Scene.h:10-11) from whichever copy the layout keeps
-__device__ __forceinline__ void fetch_material(const SceneLds& sc, int idx, F3& emis, F3& scol) {
+__device__ __forceinline__ void fetch_material(const SceneLds& sc, int idx, F3& emis, F3& scol, float* lum_col = nullptr) {
   if (sc.lean) {
     const pt_sphere* sp = sc.global + idx;
     emis = mk3(sp->emission[0], sp->emission[1], sp->emission[2]);
     scol = mk3(sp->color[0], sp->color[1], sp->color[2]);
+    if (lum_col) *lum_col = luminance(scol);
   } else {
     const float4 m0 = sc.mat0[idx];
     const float4 m1 = sc.mat1[idx];
     emis = mk3(m0.x, m0.y, m0.z);
     scol = mk3(m0.w, m1.x, m1.y);
+    if (lum_col) *lum_col = m1.z;  // luminance(scol), evaluated once per sphere when the scene was staged: same operands, same bits
   }
 }
 

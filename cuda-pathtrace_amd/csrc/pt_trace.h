@@ -25,7 +25,8 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
   }
   const float4 g = sc.geom_lane(idx);
   F3 emis, scol;
-  fetch_material(sc, idx, emis, scol);
+  float lum_col = 0.0f;
+  fetch_material(sc, idx, emis, scol, n == 0 ? &lum_col : nullptr);
   F3 normal;
   float u_az, u_el;
   if constexpr (VAR >= 6) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
     L.albedo = L.albedo + scol;
     L.depth += t;
     welford_update(var[1], luminance(normal));
-    welford_update(var[2], luminance(scol));
+    welford_update(var[2], lum_col);
     welford_update(var[3], t);
   }
   return true;
