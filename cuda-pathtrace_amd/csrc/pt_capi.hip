@@ -413,8 +413,9 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   PT_HIP(hipFuncGetAttributes(&fa, fast ? pt_fast_kernel_symbol(r->opts.rng_mode, n_spheres, r->opts.max_bounces)
                                         : pt_kernel_symbol(r->opts.rng_mode, variant, n_spheres, r->opts.max_bounces,
                                                            r->opts.layout == PT_LAYOUT_PLANAR)));
-  info->block_threads = PT_BLOCK_THREADS;
-  info->grid_blocks = (int)((r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+  const int block = fast ? PT_BLOCK_THREADS : pt_kernel_block_threads(variant);
+  info->block_threads = block;
+  info->grid_blocks = (int)((r->tile_pixels + block - 1) / block);
   info->lds_bytes = (int)(fast ? pt_fast_kernel_lds_bytes(n_spheres) : pt_kernel_lds_bytes(n_spheres, variant));
   info->variant = variant;
   if (variant == 8 || variant == 9)

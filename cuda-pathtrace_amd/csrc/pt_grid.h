@@ -43,7 +43,10 @@ namespace pt {
 #define PT_GRID_CELLS_PER_SPHERE 2.0f
 #endif
 constexpr int kGridMaxCells = PT_GRID_MAX_CELLS;
-constexpr int kGridMaxItems = 8192;
+#ifndef PT_GRID_MAX_ITEMS
+#define PT_GRID_MAX_ITEMS 8192
+#endif
+constexpr int kGridMaxItems = PT_GRID_MAX_ITEMS;
 constexpr int kGridMaxBig = 64;
 constexpr int kGridMaxSpheres = PT_GRID_MAX_SPHERES;  // geometry of all spheres is staged (16 B each)
 constexpr int kGridBuildThreads = 1024;
@@ -110,8 +113,12 @@ __device__ __forceinline__ int f2ord(float f) {  // order-preserving float -> in
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : (int)(0x80000000u - (uint32_t)i)); }
 
+// eye_valid != 0: the camera position of the frame.  It only sizes the ADMISSION radius (header far2): every ray is checked
+// against far2 before it may use the grid, and the registration margins below are derived from that same radius, so a
+// wrong or missing hint costs time (more rays on the brute-force path, or fatter registrations), never correctness.
 __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_sphere* __restrict__ spheres, int n,
-                                                                         uint32_t* __restrict__ accel) {
+                                                                         uint32_t* __restrict__ accel, float eye_x, float eye_y,
+                                                                         float eye_z, int eye_valid) {
   __shared__ uint32_t cnt[kGridMaxCells + 1];
   __shared__ uint32_t scan_tmp[kGridBuildThreads];
   __shared__ int bb[6];
@@ -119,6 +126,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
   __shared__ uint32_t n_small, n_big, total;
   __shared__ float s_cs;
   __shared__ uint32_t s_dims[3];
+  __shared__ float enc[6];
   GridHeader* hdr = reinterpret_cast<GridHeader*>(accel);
   uint16_t* big = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(accel) + kGridBigOff);
   uint16_t* cell_start = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(accel) + kGridStartOff);
@@ -170,8 +178,45 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     invalid();
     return;
   }
-  const float slack = E * 0.000244140625f;          // 2^-12 E
-  const float mk = 36.0f * E * E * 9.5367431640625e-07f;  // 2^-20 (6E)^2: m_j = mk / r_j + slack
+  const float slack = E * 0.0001220703125f;         // 2^-13 E (the float DDA is off by ~2^-20 of the coordinates after 100 steps)
+  // Admission radius `far` (rays starting farther from the box centre take the brute-force loop) and D, the largest
+  // |origin - sphere centre| an admitted ray can have: origins of secondary rays lie on the scene (inside the box or on
+  // the walls around it: within E of the centre), the primary rays start at the eye.  m_j = 2^-20 D^2 / r_j + slack.
+  const float ctr[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+  // Where can a secondary ray start?  On a grid sphere (inside the box) or on one of the big spheres around it (the
+  // walls).  Six axis rays from the box centre against the big spheres measure that enclosure (an estimate: it only has
+  // to be good enough that few rays start beyond `far`); a direction without a big sphere counts the box face.
+  if (tid < 6) {
+    const int ax = tid >> 1;
+    const float sg = (tid & 1) ? -1.0f : 1.0f;
+    float best = 3.0e38f;
+    for (int i = 0; i < n; i++) {
+      const pt_sphere sp = spheres[i];
+      if (!(sp.radius > r_big)) continue;
+      const double ox = (double)ctr[0] - sp.pos[0], oy = (double)ctr[1] - sp.pos[1], oz = (double)ctr[2] - sp.pos[2];
+      const double hb = sg * (ax == 0 ? ox : (ax == 1 ? oy : oz));  // dot(dir, off), |dir| = 1
+      const double cc = ox * ox + oy * oy + oz * oz - (double)sp.radius * sp.radius;
+      const double disc = hb * hb - cc;
+      if (disc < 0.0) continue;
+      const double sq = sqrt(disc), t0 = -hb - sq, t1 = -hb + sq;
+      const double t = t0 > 0.0 ? t0 : t1;
+      if (t > 0.0 && t < (double)best) best = (float)t;
+    }
+    const float face = 0.5f * (hi[ax] - lo[ax]);
+    enc[tid] = best < 3.0e38f ? best : face;
+  }
+  __syncthreads();
+  const float enx = fmaxf(enc[0], enc[1]), eny = fmaxf(enc[2], enc[3]), enz = fmaxf(enc[4], enc[5]);
+  float far = fminf(fmaxf(1.03125f * sqrtf(enx * enx + eny * eny + enz * enz), E), 5.0f * E);  // never beyond the old fixed 5 E
+  if (eye_valid) {
+    const float ex = eye_x - ctr[0], ey = eye_y - ctr[1], ez = eye_z - ctr[2];
+    const float de = sqrtf(ex * ex + ey * ey + ez * ez);
+    if (de == de && de < 1e15f) far = fmaxf(far, 1.0625f * de);  // the primary rays
+  } else {
+    far = 5.0f * E;  // without a camera hint: generous
+  }
+  const float D = far + 0.875f * E;                 // + half the box diagonal (<= sqrt(3)/2 E)
+  const float mk = D * D * 9.5367431640625e-07f;    // 2^-20 D^2
   const float r_small = E * 0.001953125f;           // below 2^-9 E the inflation would dwarf the sphere
   auto margin = [&](float r) { return mk / r + slack; };
   auto in_grid = [&](float r) { return r >= r_small && r <= r_big; };
@@ -193,8 +238,9 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
   const float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
   float cs = fmaxf(cbrtf(sx * sy * sz / (PT_GRID_CELLS_PER_SPHERE * (float)n_small)), 2.0f * r_ref);
   for (int attempt = 0; attempt < 12; attempt++) {
-    const uint32_t nx = (uint32_t)fminf(ceilf(sx / cs), 1024.0f), ny = (uint32_t)fminf(ceilf(sy / cs), 1024.0f),
-                   nz = (uint32_t)fminf(ceilf(sz / cs), 1024.0f);
+    // at most 512 cells along one axis: the traversal keeps its three remaining-cell counters in one register (10 bits each)
+    const uint32_t nx = (uint32_t)fminf(ceilf(sx / cs), 512.0f), ny = (uint32_t)fminf(ceilf(sy / cs), 512.0f),
+                   nz = (uint32_t)fminf(ceilf(sz / cs), 512.0f);
     const uint32_t ncells = (nx < 1 ? 1 : nx) * (ny < 1 ? 1 : ny) * (nz < 1 ? 1 : nz);
     bool ok = ncells <= (uint32_t)kGridMaxCells;
     if (ok) {
@@ -318,10 +364,10 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     h.cs = cs;
     h.inv_cs = inv;
     h.slack = slack;
-    h.cx = 0.5f * (lo[0] + hi[0]);
-    h.cy = 0.5f * (lo[1] + hi[1]);
-    h.cz = 0.5f * (lo[2] + hi[2]);
-    h.far2 = 25.0f * E * E;
+    h.cx = ctr[0];
+    h.cy = ctr[1];
+    h.cz = ctr[2];
+    h.far2 = far * far;
     h.n_big = n_big;
     h.n_items = total;
     *hdr = h;
@@ -329,6 +375,15 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
 }
 
 // ---- traversal ---------------------------------------------------------------------------------------
+#ifdef PT_GRID_STATS  // instrumentation build only (tools/grid_stats.py): what the walk loop does per wave
+// [0] walks (wave level), [1] test trips, [2] lanes testing summed over trips, [3] step rounds, [4] lanes stepping summed
+// over rounds, [5] lanes that entered the walk, [6] ambiguous lanes (literal loop)
+__device__ unsigned long long g_grid_stats[8];
+#define PT_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); /* evaluated by the whole wave */ \
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_grid_stats[i], v_); } while (0)
+#else
+#define PT_STAT(i, v) do { } while (0)
+#endif
 struct Near2 {
   float T1, T2;  // two smallest estimates of 2a*t
   int i1;
@@ -336,54 +391,72 @@ struct Near2 {
 };
 
 // one sphere for one lane: the float part and the estimate of intersect_scene_screened_large, predicated
-__device__ __forceinline__ void near2_test(Near2& s, const float4 g, int i, bool en, F3 o, F3 d, const RayConst& rc,
-                                           float Tlim_hi) {
+__device__ __forceinline__ void near2_test(Near2& s, const float4 g, int i, F3 o, F3 d, float a4, float Tlim_hi) {
   const float INF = __builtin_inff();
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
   const float b = 2.0f * dot(d, off);
   const float c = dot(off, off) - g.w;
   const float bb = b * b;
-  const float a4c = rc.a4 * c;
-  const float dacc = fmaf(-rc.a4, c, bb);
+  const float a4c = a4 * c;
+  const float dacc = fmaf(-a4, c, bb);
   // a sphere can sit in several cells: the current leader must not be entered again as its own runner-up
-  const bool cand = en & ((int)__float_as_uint(dacc) >= 0) & !((i == s.i1) & (s.T1 < INF));
+  const bool cand = ((int)__float_as_uint(dacc) >= 0) & !((i == s.i1) & (s.T1 < INF));
   const float sq = __builtin_amdgcn_sqrtf(dacc);
   const float q = b + copysignf(sq, b);
   const float e = fmaf(b, b, -bb);
   const float num = a4c + e;
   const float TA = -q;
   const float TB = -num * __builtin_amdgcn_rcpf(q);
-  const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
-  const float T = lo > 0.0f ? lo : hi;
+  // the root the reference returns: origin inside (c < 0) the larger, outside the smaller (screen_sphere, pt_intersect.h)
+  const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));
+  const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
   const bool ok = cand & ((int)__float_as_uint(T) >= 0) & (T < Tlim_hi);
   const float m = fabsf(a4c) * 4.7683716e-07f;  // 2^-21 |4ac|
   s.unsure = s.unsure | (cand & !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m));
   const float Te = ok ? T : INF;
-  const bool c1 = Te < s.T1, c2 = Te < s.T2;
-  s.T2 = c1 ? s.T1 : (c2 ? Te : s.T2);
-  s.i1 = c1 ? i : s.i1;
-  s.T1 = c1 ? Te : s.T1;
+  s.i1 = Te < s.T1 ? i : s.i1;
+  s.T2 = __builtin_amdgcn_fmed3f(s.T1, s.T2, Te);  // the second smallest of {T1, T2, Te} (T1 <= T2 always)
+  s.T1 = fminf(s.T1, Te);
 }
 
-__device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, const RayConst& rc,
+// Nearest hit through the grid.  Loop shape ("test-major"): every trip of the main loop tests ONE registered sphere for
+// every lane that is still walking; a lane that has used up its cell's list moves on -- in the small inner loop, which runs
+// until every walking lane stands in a non-empty cell again (or has left the grid / met its stop condition).  A lane's trip
+// count is its number of sphere tests, not tests + cells, and a wave never waits for the longest CELL LIST of the moment
+// (the previous shape: one cell per trip, an inner loop over the longest list among the 64 lanes -- 6 750 VALU instructions
+// per wave and bounce at 1000 spheres, a third of the lanes testing at any time).
+// One step costs ~22 instructions: the exit face is the smallest tmax; the linear cell index moves by a per-ray stride and
+// the three "cells left before the box ends" counters sit in one register, 10 bits each with a guard bit on top of each
+// field (a decrement that clears a guard bit has left the box), so no per-axis cell coordinates or bounds tests are kept.
+// (The ray's FP64 constants are formed AFTER the walk: six registers the loop does not have to carry.)
+__device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
                                                      float& t_hit, int& idx) {
   const float INF = __builtin_inff();
-  const float two_a = 2.0f * rc.a;
+  const float two_a = 2.0f * a, a4 = 4.0f * a;
   const float Tlim = 1000000.0f * two_a;
   const float Tlim_hi = Tlim * 1.0000153f;
   Near2 s{INF, INF, 0, false};
   // spheres outside the grid (walls, very large or very small ones): every lane tests all of them
-  for (int k = 0; k < (int)G.h.n_big; k++) {
-    const int i = (int)G.big[k];
-    near2_test(s, G.geom[i], i, true, o, d, rc, Tlim_hi);
+  {
+    const int nb = (int)G.h.n_big;  // wave-uniform
+    int k = 0;
+    for (; k + 2 <= nb; k += 2) {  // in pairs: two independent dependency chains per trip
+      const int i = (int)G.big[k], j = (int)G.big[k + 1];
+      const float4 gi = G.geom[i], gj = G.geom[j];
+      near2_test(s, gi, i, o, d, a4, Tlim_hi);
+      near2_test(s, gj, j, o, d, a4, Tlim_hi);
+    }
+    if (k < nb) {
+      const int i = (int)G.big[k];
+      near2_test(s, G.geom[i], i, o, d, a4, Tlim_hi);
+    }
   }
-  const bool admitted = true;  // (the caller has sent the other rays to the brute-force loop)
   // clip against the grid box
   const float gmin[3] = {G.h.ox, G.h.oy, G.h.oz};
   const float dims_f[3] = {(float)G.h.nx, (float)G.h.ny, (float)G.h.nz};
   const int dims[3] = {(int)G.h.nx, (int)G.h.ny, (int)G.h.nz};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-  const float tiny = __builtin_amdgcn_sqrtf(rc.a) * 9.094947e-13f;  // 2^-40 |d|
+  const float tiny = __builtin_amdgcn_sqrtf(a) * 9.094947e-13f;  // 2^-40 |d|
   float inv[3], t_in = 0.0f, t_out = INF;
   bool par[3];
 #pragma unroll
@@ -398,65 +471,114 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
     t_in = fmaxf(t_in, tn);
     t_out = fminf(t_out, tf);
   }
-  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(rc.a);
-  bool active = admitted & (t_in <= t_out + slack_t) & (t_in * two_a < Tlim_hi);
+  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(a);
+  bool active = (t_in <= t_out + slack_t) & (t_in * two_a < Tlim_hi);
   // entry cell and DDA state
-  int cell[3], step[3];
-  float tmax[3], tdel[3];
+  float tmax0 = INF, tmax1 = INF, tmax2 = INF, tdel0 = INF, tdel1 = INF, tdel2 = INF;
+  int cidx = 0;
+  int cs0 = 0, cs1 = 0, cs2 = 0;   // what one step along the axis adds to the linear cell index (three scalars, NOT an array:
+                                   // a select between array elements becomes an indexed load from scratch memory)
+  uint32_t left = 0x20080200u;     // per axis: cells left before the box ends, bits 10k..10k+8, guard bit 10k+9
+  const int stride[3] = {1, dims[0], dims[0] * dims[1]};
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const float p = oo[k] + dd[k] * t_in;
     int ci = (int)floorf((p - gmin[k]) * G.h.inv_cs);
     ci = ci < 0 ? 0 : (ci >= dims[k] ? dims[k] - 1 : ci);
-    cell[k] = ci;
-    step[k] = par[k] ? 0 : (dd[k] > 0.0f ? 1 : -1);
-    const float bnd = gmin[k] + (float)(ci + (dd[k] > 0.0f ? 1 : 0)) * G.h.cs;
-    tmax[k] = par[k] ? INF : (bnd - oo[k]) * inv[k];
-    tdel[k] = par[k] ? INF : G.h.cs * fabsf(inv[k]);
+    const bool fwd = dd[k] > 0.0f;
+    const float bnd = gmin[k] + (float)(ci + (fwd ? 1 : 0)) * G.h.cs;
+    const float tm = par[k] ? INF : (bnd - oo[k]) * inv[k];   // a parallel axis is never the exit face
+    const float td = par[k] ? INF : G.h.cs * fabsf(inv[k]);
+    if (k == 0) { tmax0 = tm; tdel0 = td; }
+    if (k == 1) { tmax1 = tm; tdel1 = td; }
+    if (k == 2) { tmax2 = tm; tdel2 = td; }
+    cidx += ci * stride[k];
+    const int sk = fwd ? stride[k] : -stride[k];
+    if (k == 0) cs0 = sk;
+    if (k == 1) cs1 = sk;
+    if (k == 2) cs2 = sk;
+    left |= (uint32_t)(fwd ? dims[k] - 1 - ci : ci) << (10 * k);
   }
-  int c = (cell[2] * dims[1] + cell[1]) * dims[0] + cell[0];
-  c = active ? c : 0;
-  uint32_t k0 = G.cell_start[c], k1 = G.cell_start[c + 1];
+  // (Written without a lambda on purpose: captured by reference, cs0..2 stayed addressable and the step's select became a
+  // select of ADDRESSES followed by a load from scratch memory -- hundreds of cycles in the innermost loop.)
+  cidx = active ? cidx : 0;
+  uint32_t k0 = G.cell_start[cidx], k1 = G.cell_start[cidx + 1];  // the list of the cell being tested
   if (!active) k1 = k0;
-  while (active) {
-    if (k0 < k1) {
-      const int i = (int)G.items[k0];
-      k0++;
-      near2_test(s, G.geom[i], i, true, o, d, rc, Tlim_hi);
-    }
-    if (k0 >= k1) {  // cell finished: leave through the nearest wall
-      const float t_exit = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
-      const float reach = (t_exit - slack_t) * two_a;
-      if ((s.T1 * 1.0000077f < reach) | (reach > Tlim_hi)) {
-        active = false;  // nothing that could still matter lies beyond
-      } else {
-        const int ax = (tmax[0] <= tmax[1]) ? ((tmax[0] <= tmax[2]) ? 0 : 2) : ((tmax[1] <= tmax[2]) ? 1 : 2);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          if (ax == k) {
-            cell[k] += step[k];
-            tmax[k] += tdel[k];
-            if ((cell[k] < 0) | (cell[k] >= dims[k]) | (step[k] == 0)) active = false;
-          }
-        }
-        if (active) {
-          c = (cell[2] * dims[1] + cell[1]) * dims[0] + cell[0];
-          k0 = G.cell_start[c];
-          k1 = G.cell_start[c + 1];
+  uint32_t n0 = 0, n1 = 0;  // the list of the NEXT cell, fetched ahead of need (valid while have_next)
+  bool have_next = false;
+#ifdef PT_TIMING_ONLY_NO_WALK   // never defined in a shipped build: what the kernel costs without the grid walk
+  active = false;
+  k1 = k0;
+#endif
+  bool walking = active;    // the DDA can still move on: neither stopped nor out of the box
+  // (Written without a lambda on purpose: captured by reference, cs0..2 stayed addressable and the step's select became a
+  // select of ADDRESSES followed by a load from scratch memory -- hundreds of cycles in the innermost loop.)
+  PT_STAT(0, 1);
+  PT_STAT(5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+  for (;;) {
+    // Stepping is done one cell AHEAD and for the whole wave at once: a round is triggered only when some lane has used
+    // up its list and has no next one in hand, and in that round EVERY lane without a next list takes its step.  (One
+    // round per lane and cell as they came due cost 55 rounds per walk with 5 of 64 lanes stepping in each.)  The stop rule
+    // is evaluated when the step is taken, i.e. possibly before the current cell's tests have lowered T1: at worst one
+    // cell more is visited than strictly needed -- more tests, same result.
+    for (;;) {
+      const bool swap = (k0 >= k1) & have_next;
+      k0 = swap ? n0 : k0;
+      k1 = swap ? n1 : k1;
+      have_next = have_next & !swap;
+      const bool starving = walking & (k0 >= k1);  // have_next is false here for such a lane
+      if (__builtin_amdgcn_ballot_w64(starving) == 0) break;
+      const bool step = walking & !have_next;
+      PT_STAT(3, 1);
+      PT_STAT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(step)));
+      if (step) {
+        const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
+        const float reach = (t_exit - slack_t) * two_a;
+        // nothing that could still matter lies beyond the cell being left: stop (same rule as before)
+        const bool stop = (s.T1 * 1.0000077f < reach) | (reach > Tlim_hi);
+        const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
+        const bool a1 = !a0 & (tmax1 <= tmax2);
+        tmax0 = a0 ? tmax0 + tdel0 : tmax0;
+        tmax1 = a1 ? tmax1 + tdel1 : tmax1;
+        tmax2 = (a0 | a1) ? tmax2 : tmax2 + tdel2;
+        cidx += a0 ? cs0 : (a1 ? cs1 : cs2);
+        left -= a0 ? 1u : (a1 ? (1u << 10) : (1u << 20));
+        walking = !stop & ((left & 0x20080200u) == 0x20080200u);
+        if (walking) {
+          n0 = G.cell_start[cidx];
+          n1 = G.cell_start[cidx + 1];
+          have_next = true;
         }
       }
+    }
+    const bool testing = k0 < k1;
+    if (__builtin_amdgcn_ballot_w64(testing) == 0) break;  // no lane has a list left, and none can get one
+    PT_STAT(1, 1);
+    PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(testing)));
+    if (testing) {
+      // Two registered spheres per trip where the list has two left: the loop is latency-bound (dependent LDS reads, a
+      // 25-deep dependency chain per test, four waves per SIMD), so the second test's chain runs in the shadow of the first.
+      const bool two = k0 + 1u < k1;
+      const int i = (int)G.items[k0];
+      const int j = (int)G.items[two ? k0 + 1u : k0];
+      const float4 gi = G.geom[i], gj = G.geom[j];
+      k0 += two ? 2u : 1u;
+      near2_test(s, gi, i, o, d, a4, Tlim_hi);
+      if (two) near2_test(s, gj, j, o, d, a4, Tlim_hi);
     }
   }
   const bool has = s.T1 < INF;
   bool ambiguous = s.unsure | (has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f)));
   float t;
   bool bad = false;
+  const RayConst rc = make_ray_const(d);
   const bool real = intersect_sphere_nb(o, d, rc, G.geom[s.i1], t, bad);
   const bool good = real & (t > 0.0f) & (t < 1000000.0f);
   ambiguous = ambiguous | (has & (bad | !good));
   t_hit = t;
   idx = s.i1;
   bool hit = has & good;
+  PT_STAT(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(ambiguous)));
   if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
   return hit;
 }
@@ -464,17 +586,18 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
 // variant 11's nearest-hit search: the grid when the build produced one, the brute-force loop otherwise
 __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   if (n <= 0) return false;
-  const RayConst rc = make_ray_const(d);
+  const float a = dot(d, d);
   const GridLds& G = *sc.grid;
   if (G.valid) {
     // admitted rays only: finite, and starting within 5 E of the grid centre (the registration margins assume it)
     const F3 oc = mk3(o.x - G.h.cx, o.y - G.h.cy, o.z - G.h.cz);
     const float INF = __builtin_inff();
-    const bool admitted = (dot(oc, oc) <= G.h.far2) & (rc.a > 0.0f) & (rc.a < 1e30f) & (fabsf(d.x) < INF) & (fabsf(d.y) < INF) &
+    const bool admitted = (dot(oc, oc) <= G.h.far2) & (a > 0.0f) & (a < 1e30f) & (fabsf(d.x) < INF) & (fabsf(d.y) < INF) &
                           (fabsf(d.z) < INF);
-    if (admitted) return intersect_scene_grid(sc, G, n, o, d, rc, t_hit, idx);
+    PT_STAT(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);  // waves that also run the brute-force loop
+    if (admitted) return intersect_scene_grid(sc, G, n, o, d, a, t_hit, idx);
   }
-  return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
+  return intersect_scene_screened_large(sc, n, o, d, make_ray_const(d), t_hit, idx);
 }
 
 }  // namespace pt

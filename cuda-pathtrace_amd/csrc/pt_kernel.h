@@ -41,6 +41,16 @@
 #define PT_LDS_BUDGET_BYTES (96 * 1024)
 // Variant 11 (uniform grid, pt_grid.h) stages the geometry of every sphere (16 B each) beside its tables; it pays from
 // about 200 spheres (150 spheres + walls: 3.2 vs 3.0-3.3 ms, 300: 5.9 vs 4.3, 1000: 18.1 vs 7.6; tools/grid_check.py).
+#ifndef PT_GRID_BLOCK_THREADS
+// The grid kernel (variant 11) is latency-bound -- dependent LDS reads and a long dependency chain per sphere test -- so it
+// wants WAVES, and its 36 KB LDS image (geometry + tables at 1000 spheres) is per workgroup: 256-thread workgroups stop at
+// four per CU (4 waves per SIMD).  512-thread workgroups share one image between eight waves; with the register cap below
+// six waves per SIMD fit (three workgroups, 108 KB).  Measured at 1000 spheres, 32 spp: 256/4 27.0 ms, see DESIGN.md.
+#define PT_GRID_BLOCK_THREADS 512
+#endif
+#ifndef PT_GRID_MIN_WAVES
+#define PT_GRID_MIN_WAVES 6  // __launch_bounds__ 2nd argument of the grid kernel: <= 80 VGPRs
+#endif
 #define PT_GRID_MAX_SPHERES 2048
 #define PT_GRID_MIN_SPHERES 192
 
@@ -72,12 +82,13 @@ struct PixelKernelArgs {
 #define PT_VARIANT_FAST 100     // reported by pt_renderer_kernel_info for a fast_math renderer (pt_fast.hip)
 #define PT_FAST_LDS_SPHERES 64  // the fast kernel stages scenes up to this size into LDS, larger ones are read in place
 int pt_kernel_num_variants(void);
+int pt_kernel_block_threads(int variant);  // workgroup size the launcher uses
 bool pt_kernel_has_variant(int variant);  // compiled into this library?
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);
-hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, hipStream_t stream);
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */, hipStream_t stream);
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);

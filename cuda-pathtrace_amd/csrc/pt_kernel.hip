@@ -16,8 +16,13 @@ namespace pt {
 // 9-sphere kernels carry no trace of it.
 // REF builds the kernel for the reference's own configuration -- 9 spheres (Scene.h:23), MAX_BOUNCES 5 (pathtrace.cu:7) -- as
 // compile-time constants: no generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
+template <int VAR>
+constexpr int kBlockThreads = (VAR == 11) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
+template <int VAR>
+constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : PT_MIN_WAVES;
+
 template <int RNG, int VAR, bool LEAN = false, bool REF = false>
-__global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+__global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   if constexpr (REF) {
     a.n_spheres = 9;
     a.max_bounces = 5;
@@ -34,7 +39,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_MIN_WAVES) PT_KERNEL_ATTR
     sc.grid = &grid;
   }
 
-  const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;  // pixel index inside the tile
+  const uint32_t tp = blockIdx.x * kBlockThreads<VAR> + threadIdx.x;  // pixel index inside the tile
   const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
   const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
   const int col = (int)(tp % (uint32_t)a.width);
@@ -475,7 +480,18 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool 
   }
 }
 
+#ifdef PT_GRID_STATS
+extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_grid_stats), sizeof(zero)) != hipSuccess) return -2;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pt::g_grid_stats), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
 int pt_kernel_num_variants(void) { return 12; }
+
+int pt_kernel_block_threads(int variant) { return variant == 11 ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
 
 bool pt_kernel_has_variant(int variant) {
   if (variant < 0 || variant >= 12) return false;
@@ -503,8 +519,9 @@ int pt_kernel_max_spheres(int variant) {
   return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
 }
 
-hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, hipStream_t stream) {
-  hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel);
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, hipStream_t stream) {
+  hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel, eye ? eye[0] : 0.0f,
+                     eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -521,12 +538,13 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   }
   if (variant == 11) {  // this frame's grid (the scene may have changed since the last one)
     if (!a.accel) return hipErrorInvalidValue;
-    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), stream);
+    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, stream);
     if (e != hipSuccess) return e;
   }
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);
-  const unsigned grid = (unsigned)((lanes + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK_THREADS), lds, stream, b);
+  const unsigned block = (unsigned)pt_kernel_block_threads(variant);
+  const unsigned grid = (unsigned)((lanes + block - 1) / block);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds, stream, b);
   return hipGetLastError();
 }
 
