@@ -351,6 +351,12 @@ def main():
                         "fp64_tflops": round(vrec["flops_fp64_per_launch"] / kernel_s / 1e12, 2),
                         "source": f"{vrec.get('source')} (rocprofv3 SQ_INSTS_VALU per launch / this run's kernel time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles "
                                   "per wave64 instruction, MI355X_MICROARCH.md)"}
+                cw = vrec.get("class_weighted")
+                if cw:  # what the kernel's own instruction mix can reach: half-rate and transcendental classes cost 4.1 / 8.1 / 16.2 cycles
+                    valu["class_weighted"] = {"frac": cw["frac"], "costs_cycles": cw["costs_cycles"], "mix_per_sample": cw["static_mix_per_sample"],
+                                              "clock_ghz": cw["clock_ghz"],
+                                              "note": "SIMD cycles the measured mix needs / SIMD cycles the kernel took, both from the profiled run "
+                                                      "(tools/issue_model.py, costs measured by tools/ubench/valu_clock)"}
         out = {
             "metric": f"Msamples/s, 9-sphere Cornell box {WIDTH}x{HEIGHT}x{spp}spp",
             "value": round(total_samples / elapsed / 1e6, 2),

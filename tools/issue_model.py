@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Class-weighted VALU issue model of the headline kernel: how many SIMD cycles its instruction mix NEEDS, with the issue
+costs measured on this chip by tools/ubench/valu_clock (profiles/r02/valu_issue_cost_ubench.txt), against the SIMD cycles
+the kernel TOOK (kernel time x the clock GRBM_GUI_ACTIVE reports).
+
+  full-rate  (v_add/sub/mul/fma_f32, v_mov, and/or/xor/not, 32-bit integer add/sub)                      2.2 cycles
+  half-rate  (compare, cndmask, min/max/med3, bfi/bitop3, shifts, cvt, every FP64 add/mul/fma, ...)        4.1
+  f32 transcendental (rcp, rsq, sqrt)                                                                      8.1
+  f64 transcendental                                                                                      16.2
+
+The mix is counted statically in the ISA of the hot path (the sample loop up to its first cold block -- the literal-loop
+fallbacks behind the rare redo branches); the count agrees with SQ_INSTS_VALU per sample to 0.3 %.
+Usage: issue_model.py <isa.s> <kernel symbol substring> <profile json (profiles/rNN/tag.json)> <key in valu_roofline.json>"""
+import collections, json, os, sys
+
+isa, sym, prof, key = sys.argv[1:5]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COST = {"full": 2.2, "half": 4.1, "trans32": 8.1, "trans64": 16.2}
+FULL = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mov_b32",
+        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
+T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32")
+T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
+lines = open(isa).read().split("\n")
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and sym in l and l.split(";")[0].rstrip().endswith(":"))
+body = []
+for l in lines[start + 1:]:
+    if l.startswith(".Lfunc_end"):
+        break
+    body.append(l)
+loop = next(i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l)      # the sample loop
+cold = next(i for i, l in enumerate(body) if i > loop and "Depth=2" in l)              # first literal-loop fallback block
+cnt = collections.Counter()
+for l in body[loop:cold]:
+    t = l.strip().split()
+    if not t or not t[0].startswith("v_"):
+        continue
+    op = t[0]
+    cnt["trans64" if op.startswith(T64) else "trans32" if op.startswith(T32) else "full" if op.startswith(FULL) else "half"] += 1
+need = sum(cnt[k] * COST[k] for k in cnt)
+d = json.load(open(os.path.join(root, prof)))
+c, v = d["pmc_per_launch_avg"], d["valu"]
+samples = d.get("samples_per_launch") or 2 ** 30
+clock = c["GRBM_GUI_ACTIVE"] / 8 / (v["kernel_ms"] * 1e-3)  # the counter sums the 8 XCDs
+took = v["kernel_ms"] * 1e-3 * clock * 1024 / (samples / 64)
+rec = {"costs_cycles": COST, "static_mix_per_sample": dict(cnt), "static_valu_per_sample": sum(cnt.values()),
+       "measured_valu_per_sample": c["SQ_INSTS_VALU"] / (samples / 64), "needed_simd_cycles_per_sample": round(need, 1),
+       "clock_ghz": round(clock / 1e9, 4), "taken_simd_cycles_per_sample": round(took, 1), "frac": round(need / took, 4),
+       "method": "tools/issue_model.py; costs from tools/ubench/valu_clock (profiles/r02/valu_issue_cost_ubench.txt)"}
+vp = os.path.join(root, "profiles", "valu_roofline.json")
+r = json.load(open(vp))
+r[key]["class_weighted"] = rec
+json.dump(r, open(vp, "w"), indent=1)
+print(json.dumps(rec))
