@@ -387,10 +387,14 @@ __device__ __forceinline__ float quotient_to_float_nb(double num, const RayConst
 
 // intersect_sphere for a sphere already known to satisfy det >= 0 is NOT assumed: the float part
 // is recomputed and `real` returned exactly as the literal test would.
+__device__ __forceinline__ bool intersect_sphere_nb_oc(F3 off, float c, F3 d, const RayConst& rc, float& t, bool& bad);
 __device__ __forceinline__ bool intersect_sphere_nb(F3 o, F3 d, const RayConst& rc, float4 g, float& t, bool& bad) {
-  F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  return intersect_sphere_nb_oc(off, dot(off, off) - g.w, d, rc, t, bad);
+}
+// the same with off = o - centre and c = dot(off, off) - r*r supplied (primary rays: staged once per workgroup)
+__device__ __forceinline__ bool intersect_sphere_nb_oc(F3 off, float c, F3 d, const RayConst& rc, float& t, bool& bad) {
   float b = 2.0f * dot(d, off);
-  float c = dot(off, off) - g.w;
   float bb = b * b;
   float det = bb - rc.a4 * c;
   double disc = (double)bb - rc.a4d * (double)c;

@@ -113,12 +113,15 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
   return bi >= 0;
 }
 
+#ifndef PT_FAST_MIN_WAVES
+#define PT_FAST_MIN_WAVES 4  // 117 VGPRs; 5 or 6 waves per SIMD (96 / 80 VGPRs, spills) measured no faster: issue-bound like the exact kernels
+#endif
 template <int RNG, int NS, int NB>
-__global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_fast(PixelKernelArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_kernel_fast(PixelKernelArgs a) {
   if constexpr (NS > 0) a.n_spheres = NS;
   if constexpr (NB > 0) a.max_bounces = NB;
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES);
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES, mk3(a.eye[0], a.eye[1], a.eye[2]));
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
   const bool active = tp < a.tile_pixels;
@@ -284,14 +287,14 @@ const void* pt_fast_kernel_symbol(int rng_mode, int n_spheres, int max_bounces) 
 }
 
 size_t pt_fast_kernel_lds_bytes(int n_spheres) {
-  const size_t scene = n_spheres > PT_FAST_LDS_SPHERES ? 0 : (size_t)n_spheres * 3 * sizeof(float4);
+  const size_t scene = n_spheres > PT_FAST_LDS_SPHERES ? 0 : (size_t)n_spheres * 4 * sizeof(float4);
   return scene + (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
 
 hipError_t pt_launch_fast_kernel(const PixelKernelArgs& a, int rng_mode, hipStream_t stream) {
   fast_kernel_fn fn = select_fast(rng_mode, a.n_spheres, a.max_bounces);
   PixelKernelArgs b = a;
-  b.scene_lds_f4 = a.n_spheres > PT_FAST_LDS_SPHERES ? 0u : (uint32_t)a.n_spheres * 3u;
+  b.scene_lds_f4 = a.n_spheres > PT_FAST_LDS_SPHERES ? 0u : (uint32_t)a.n_spheres * 4u;
   const size_t lds = pt_fast_kernel_lds_bytes(a.n_spheres);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);

@@ -557,7 +557,9 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
     PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(testing)));
     if (testing) {
       // Two registered spheres per trip where the list has two left: the loop is latency-bound (dependent LDS reads, a
-      // 25-deep dependency chain per test, four waves per SIMD), so the second test's chain runs in the shadow of the first.
+      // 25-deep dependency chain per test), so the second test's chain runs in the shadow of the first (-9 %).
+      // (Measured and dropped: requesting the NEXT trip's two indices before the tests, to take one LDS latency off the
+      // chain -- 3 % slower: the extra selects and the stale-list check cost more than the latency six waves already hide.)
       const bool two = k0 + 1u < k1;
       const int i = (int)G.items[k0];
       const int j = (int)G.items[two ? k0 + 1u : k0];

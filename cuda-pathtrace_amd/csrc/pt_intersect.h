@@ -196,11 +196,15 @@ struct ScreenState {
 // which spares the doubling of b per sphere: scaling by powers of two is exact, so every quantity below is exactly a
 // quarter (half for the root estimates T = a*t) of the contract-scale value it stands for, and every decision
 // (signs, relative margins, ranking) is the same one.
+__device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st);
 __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
                                               ScreenState& st) {
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  screen_sphere_oc(off, dot(off, off) - g.w, i, d, rc, imask, st);
+}
+// off = o - centre and c = dot(off, off) - r*r supplied by the caller (primary rays read them from SceneLds::eyeg)
+__device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st) {
   const float h = dot(d, off);                     // b / 2
-  const float c = dot(off, off) - g.w;
   const float hh = h * h;                          // bb / 4
   const float ac = rc.a * c;                       // 4ac / 4
   // The contract's det = RN(bb - RN(4a*c)) is used only through its sign.  dacc below rounds the exact
@@ -228,7 +232,8 @@ __device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d,
   st.k1 = st.k1 < key ? st.k1 : key;
 }
 
-template <bool NB>
+// PRIMARY: the ray starts at the eye the scene image was staged for -- off and c come from SceneLds::eyeg
+template <bool NB, bool PRIMARY = false>
 __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                               float& t_hit, int& idx) {
   if (n <= 0) return false;
@@ -238,7 +243,14 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   const uint32_t imask = (1u << ib) - 1u;
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
   ScreenState st{0xFFFFFFFFu, 0xFFFFFFFFu, false};
-  auto screen = [&](const float4 g, int i) { screen_sphere(g, i, o, d, rc, imask, st); };
+  auto screen = [&](const float4 g, int i) {
+    if constexpr (PRIMARY) {
+      const float4 e = sc.eyeg[i];
+      screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, i, d, rc, imask, st);
+    } else {
+      screen_sphere(g, i, o, d, rc, imask, st);
+    }
+  };
   // Manually unrolled by three (hipcc does not runtime-unroll this loop on request): the three
   // LDS reads are issued together and the three dependency chains interleave, which is what
   // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
@@ -267,7 +279,13 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
     const int i1 = (int)(k1 & imask);
     float t;
     bool bad = false;
-    const bool real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
+    bool real;
+    if constexpr (PRIMARY) {
+      const float4 e = sc.eyeg[has ? i1 : 0];
+      real = intersect_sphere_nb_oc(mk3(e.x, e.y, e.z), e.w, d, rc, t, bad);
+    } else {
+      real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
+    }
     const bool good = real & (t > 0.0f) & (t < 1000000.0f);
     ambiguous = ambiguous | (has & (bad | !good));
     hit = has & good;
@@ -415,14 +433,15 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
   return hit;
 }
 
-template <int VAR>
+template <int VAR, bool PRIMARY = false>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   const RayConst rc = make_ray_const(d);
   if constexpr (VAR >= 5) {
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
-    if (!sc.lean && (sc.small_only || n <= PT_SCREEN_MAX_SPHERES)) return intersect_scene_screened_keys<(VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+    if (!sc.lean && (sc.small_only || n <= PT_SCREEN_MAX_SPHERES))
+      return intersect_scene_screened_keys<(VAR >= 6), (PRIMARY && VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
     if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }
@@ -435,7 +454,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
 }
 
 // nearest hit for P rays at once; same decisions as intersect_scene_screened_keys<true>
-template <int P>
+template <int P, bool PRIMARY = false>
 __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const F3 (&o)[P], const F3 (&d)[P],
                                                 bool (&hit)[P], float (&t_hit)[P], int (&idx)[P]) {
   RayConst rc[P];
@@ -459,7 +478,14 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
 #if PT_UNROLL_NINE
   if (P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
 #pragma unroll
-    for (int u = 0; u < 9; u++) screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
+    for (int u = 0; u < 9; u++) {
+      if constexpr (PRIMARY) {
+        const float4 e = sc.eyeg[u];
+        screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, u, d[0], rc[0], imask, st[0]);
+      } else {
+        screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
+      }
+    }
     i = 9;
   }
 #endif
@@ -486,7 +512,13 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     const int i1 = (int)(st[p].k1 & imask);
     float t;
     bool bad = false;
-    const bool real = intersect_sphere_nb(o[p], d[p], rc[p], sc.geom[has ? i1 : 0], t, bad);
+    bool real;
+    if (PRIMARY && P == 1 && n == 9) {  // the eye image was used for the screen: use it for the exact step as well
+      const float4 e = sc.eyeg[has ? i1 : 0];
+      real = intersect_sphere_nb_oc(mk3(e.x, e.y, e.z), e.w, d[p], rc[p], t, bad);
+    } else {
+      real = intersect_sphere_nb(o[p], d[p], rc[p], sc.geom[has ? i1 : 0], t, bad);
+    }
     const bool good = real & (t > 0.0f) & (t < 1000000.0f);
     ambiguous[p] = ambiguous[p] | (has & (bad | !good));
     hit[p] = has & good;

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     a.max_bounces = 5;
   }
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]));
   // variants with a lean build run their LDS build only on scenes up to PT_SCREEN_MAX_SPHERES (launcher): the
   // many-sphere path is not even compiled into it, which keeps the hot loop's code small
   sc.small_only = !LEAN && (VAR == 6 || VAR == 8 || VAR == 10);
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   }
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN);
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]));
   sc.small_only = !LEAN && kSplit == 4;  // variant 8 has a lean build for larger scenes, variant 9 has not
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
@@ -429,7 +429,7 @@ static inline bool lds_lean(int n, int variant) {
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
   if (lds_lean(n, variant)) return 0;  // the lean builds read the caller's array directly
-  return (size_t)n * 3 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);
+  return (size_t)n * 4 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image
 }
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
@@ -515,8 +515,8 @@ int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
   if (variant == 6 || variant == 8 || variant == 10 || variant == 11) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
-  if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (4 * sizeof(float4)));
-  return (int)((PT_LDS_BUDGET_BYTES - tail) / (3 * sizeof(float4)));
+  if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - tail - 2 * sizeof(float4)) / (5 * sizeof(float4)));
+  return (int)((PT_LDS_BUDGET_BYTES - tail) / (4 * sizeof(float4)));
 }
 
 hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, hipStream_t stream) {

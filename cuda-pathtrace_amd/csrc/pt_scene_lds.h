@@ -29,6 +29,9 @@ struct SceneLds {
   float4* geom;  // {cx, cy, cz, r*r}
   float4* mat0;  // {ex, ey, ez, colx}
   float4* mat1;  // {coly, colz, luminance(col), 0}: the albedo luminance of pathtrace.cu:193 is a per-sphere constant
+  float4* eyeg;  // {eye - centre, |eye - centre|^2 - r*r}: the off and c of pathtrace.cu:73,76 for a ray that starts at the eye.
+                 // Every PRIMARY ray of the frame does, so these nine subtractions and dot products per sphere are done once
+                 // per workgroup instead of once per sample (same operands, same operations, same bits).
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
@@ -59,8 +62,8 @@ struct SceneLds {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool WITH_PAIR>
-__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, spheres, lean, false, nullptr};
+__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean, F3 eye) {
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, lds + 4 * n, spheres, lean, false, nullptr};
   const float qnan = __builtin_nanf("");
   if (lean) return s;  // nothing is staged
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -69,6 +72,8 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
     s.geom[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], rr);
     s.mat0[i] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], sp.color[0]);
     s.mat1[i] = make_float4(sp.color[1], sp.color[2], luminance(mk3(sp.color[0], sp.color[1], sp.color[2])), 0.0f);
+    const F3 off = mk3(eye.x - sp.pos[0], eye.y - sp.pos[1], eye.z - sp.pos[2]);  // :73 with origin = eye
+    s.eyeg[i] = make_float4(off.x, off.y, off.z, dot(off, off) - rr);             // :76
     if constexpr (WITH_PAIR) {
       float* pa = reinterpret_cast<float*>(s.pair + 2 * (i >> 1)) + (i & 1);
       pa[0] = sp.pos[0];

@@ -9,7 +9,8 @@ namespace pt {
 
 // One iteration of the bounce loop (src/pathtrace.cu:155-196) at depth n; false = the ray left the scene
 // (:157-161, the path's colour has been added to L.color and the path is over).
-template <int RNG, int VAR>
+// PRIMARY (only ever with n == 0): o is the eye the scene image was staged for, see SceneLds::eyeg
+template <int RNG, int VAR, bool PRIMARY = false>
 __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
                                             Rng<RNG>& rng, Welford (&var)[4], int n) {
   float t = 0.0f;
@@ -18,7 +19,7 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
   else
-    hit = intersect_scene<VAR>(sc, nsph, o, d, t, idx);
+    hit = intersect_scene<VAR, PRIMARY>(sc, nsph, o, d, t, idx);
   if (!hit) {  // :157-161
     L.color = L.color + color;
     return false;
@@ -78,8 +79,9 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
   F3 mask = mk3(1.0f, 1.0f, 1.0f);
 #if PT_UNROLL_BOUNCES
   if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
+    if (!bounce_once<RNG, VAR, true>(L, sc, nsph, o, d, color, mask, rng, var, 0)) return;  // trace_ray starts at the eye
 #pragma unroll
-    for (int n = 0; n < 5; n++)
+    for (int n = 1; n < 5; n++)
       if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
   } else
 #endif
@@ -109,9 +111,10 @@ struct PathResult {
 };
 
 // trace_ray (src/pathtrace.cu:150-201) for P paths in lockstep; results are returned, not accumulated
+// primary_at_zero: the paths start at the eye the scene image was staged for (true for every caller in pt_kernel.hip)
 template <int RNG, int P>
 __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds& sc, int nsph, F3 (&o)[P], F3 (&d)[P],
-                                            Rng<RNG> (&rng)[P], int max_bounces) {
+                                            Rng<RNG> (&rng)[P], int max_bounces, bool primary_at_zero = true) {
   F3 color[P], mask[P];
   bool alive[P];
 #pragma unroll
@@ -133,7 +136,10 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     bool hit[P];
     float t[P];
     int idx[P];
-    intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
+    if (P == 1 && primary_at_zero && n == 0)
+      intersect_paths<P, true>(sc, nsph, o, d, hit, t, idx);
+    else
+      intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
     // stage 1 (straight-line for all paths, so their chains interleave): materials, draws, fast geometry
     F3 centre[P], emis[P], scol[P];
     float u_az[P], u_el[P];
