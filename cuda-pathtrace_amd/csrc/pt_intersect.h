@@ -255,8 +255,22 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   // LDS reads are issued together and the three dependency chains interleave, which is what
   // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
   int i = 0;
+  if constexpr (PRIMARY) {
+    // the pixel footprints of this wave rule some spheres out for every primary ray (pt_footprint.h): rank only the rest.
+    // The mask is wave-uniform, so this is a scalar loop over its set bits.
+    const uint32_t full = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
+    uint32_t m = __builtin_amdgcn_readfirstlane(sc.prim_mask) & full;
+    if (m != full) {
+      while (m) {
+        const int j = __builtin_ctz(m);
+        m &= m - 1u;
+        screen(sc.geom[j], j);
+      }
+      i = n;
+    }
+  }
 #if PT_UNROLL_NINE
-  if (n == 9) {  // the reference's scene size (Scene.h:23): constant LDS offsets and indices, no loop state
+  if (i == 0 && n == 9) {  // the reference's scene size (Scene.h:23): constant LDS offsets and indices, no loop state
 #pragma unroll
     for (int u = 0; u < 9; u++) screen(sc.geom[u], u);
     i = 9;
@@ -475,8 +489,21 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   const uint32_t imask = (1u << ib) - 1u;
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);
   int i = 0;
+  if constexpr (PRIMARY && P == 1) {  // rank only the spheres the wave's pixel footprints leave (pt_footprint.h)
+    const uint32_t full = (1u << n) - 1u;
+    uint32_t m = __builtin_amdgcn_readfirstlane(sc.prim_mask) & full;
+    if (n <= 16 && m != full) {
+      while (m) {
+        const int j = __builtin_ctz(m);
+        m &= m - 1u;
+        const float4 e = sc.eyeg[j];
+        screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, j, d[0], rc[0], imask, st[0]);
+      }
+      i = n;
+    }
+  }
 #if PT_UNROLL_NINE
-  if (P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
+  if (i == 0 && P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
 #pragma unroll
     for (int u = 0; u < 9; u++) {
       if constexpr (PRIMARY) {
@@ -513,7 +540,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     float t;
     bool bad = false;
     bool real;
-    if (PRIMARY && P == 1 && n == 9) {  // the eye image was used for the screen: use it for the exact step as well
+    if (PRIMARY && P == 1 && n <= 16) {  // the eye image was used for the screen: use it for the exact step as well
       const float4 e = sc.eyeg[has ? i1 : 0];
       real = intersect_sphere_nb_oc(mk3(e.x, e.y, e.z), e.w, d[p], rc[p], t, bad);
     } else {

@@ -86,6 +86,29 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
   };
 
+  if constexpr (REF && VAR == 6) {
+#ifndef PT_NO_FOOTPRINT
+    // once per pixel: the spheres this pixel's primary rays can return; the wave ranks the union at bounce 0
+    if (a.spp >= 8) {
+      auto dir_at = [&](float sx, float sy) {
+        if (pow2_image) {
+          sx *= inv_h;
+          sy *= inv_w;
+        } else {
+          sx /= (float)a.height;
+          sy /= (float)a.width;
+        }
+        return lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
+      };
+      const uint32_t mine = active ? primary_candidates(sc, a.n_spheres, (float)row, (float)col, dir_at) : 0u;
+      uint32_t wave_mask = 0u;
+#pragma unroll
+      for (int j = 0; j < 9; j++) wave_mask |= (__builtin_amdgcn_ballot_w64(((mine >> j) & 1u) != 0u) != 0ull) ? (1u << j) : 0u;
+      sc.prim_mask = wave_mask;
+    }
+#endif
+  }
+
   int i = active ? 0 : a.spp;  // inactive lanes trace nothing
   if constexpr (kRegen) {
     // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
@@ -270,6 +293,28 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
   const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
   const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
+
+  if constexpr (REF && kSplit == 4) {
+#ifndef PT_NO_FOOTPRINT
+    if (a.spp >= 8) {  // once per pixel: the spheres its primary rays can return (pt_footprint.h); the wave ranks the union
+      auto dir_at = [&](float sx, float sy) {
+        if (pow2_image) {
+          sx *= inv_h;
+          sy *= inv_w;
+        } else {
+          sx /= (float)a.height;
+          sy /= (float)a.width;
+        }
+        return lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
+      };
+      const uint32_t mine = active ? primary_candidates(sc, a.n_spheres, (float)row, (float)col, dir_at) : 0u;
+      uint32_t wave_mask = 0u;
+#pragma unroll
+      for (int j = 0; j < 9; j++) wave_mask |= (__builtin_amdgcn_ballot_w64(((mine >> j) & 1u) != 0u) != 0ull) ? (1u << j) : 0u;
+      sc.prim_mask = wave_mask;
+    }
+#endif
+  }
 
   float sum0[kOwn], sum1[kOwn], sum2[kOwn];  // this lane's feature sums (depth uses sum0 only)
   Welford w[kOwn];

@@ -37,6 +37,7 @@ struct SceneLds {
   bool lean;     // compile-time constant after inlining
   bool small_only;  // compile-time constant: this kernel build is only launched for scenes up to PT_SCREEN_MAX_SPHERES
   const GridLds* grid;  // variant 11 only
+  uint32_t prim_mask;   // wave-uniform: the spheres the bounce-0 screen of this wave has to rank (pt_footprint.h); all ones = every sphere
 
   // geometry of sphere i, i wave-uniform
   __device__ __forceinline__ float4 geom_uniform(int i) const {
@@ -63,7 +64,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool WITH_PAIR>
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean, F3 eye) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, lds + 4 * n, spheres, lean, false, nullptr};
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, lds + 4 * n, spheres, lean, false, nullptr, 0xFFFFFFFFu};
   const float qnan = __builtin_nanf("");
   if (lean) return s;  // nothing is staged
   for (int i = threadIdx.x; i < n; i += blockDim.x) {

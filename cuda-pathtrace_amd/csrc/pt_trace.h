@@ -2,6 +2,7 @@
 // result-returning lockstep form (trace_paths + accumulate_path) used by variants 7 and 8.
 #pragma once
 #include "pt_grid.h"
+#include "pt_footprint.h"
 
 #pragma clang fp contract(off)
 
