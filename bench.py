@@ -353,7 +353,7 @@ def main():
                                   "per wave64 instruction, MI355X_MICROARCH.md)"}
                 cw = vrec.get("class_weighted")
                 if cw:  # what the kernel's own instruction mix can reach: half-rate and transcendental classes cost 4.1 / 8.1 / 16.2 cycles
-                    valu["class_weighted"] = {"frac": cw["frac"], "costs_cycles": cw["costs_cycles"], "mix_per_sample": cw["static_mix_per_sample"],
+                    valu["class_weighted"] = {"frac": cw["frac"], "costs_cycles": cw["costs_cycles"], "mix_per_sample": cw["mix_per_sample"],
                                               "clock_ghz": cw["clock_ghz"],
                                               "note": "SIMD cycles the measured mix needs / SIMD cycles the kernel took, both from the profiled run "
                                                       "(tools/issue_model.py, costs measured by tools/ubench/valu_clock)"}

@@ -15,7 +15,7 @@
 // within the Monte-Carlo standard error, and the share of pixels whose colour differs by more than 1e-4 at equal
 // seeds is bounded (a chaotic integrand: the reference compiled with and without contraction differs in ~1 % of
 // the pixels).
-#include "pt_scene_lds.h"
+#include "pt_footprint.h"
 
 #pragma clang fp contract(fast)
 
@@ -70,8 +70,9 @@ __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, cons
 // of t with the sphere index in the low bits (a negative discriminant or a negative t sets the sign bit = loses against
 // every valid key): one v_min_u32 per sphere instead of compares and selects; the winner's t is then evaluated again
 // at full precision.  Larger scenes use plain compares.
+// mask (wave-uniform): the spheres to rank -- all of them, or for a primary ray what the wave's pixel footprints leave (pt_footprint.h)
 template <int NS>
-__device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+__device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, uint32_t mask = 0xFFFFFFFFu) {
   const float a = dot3(d, d);
   const float inv_a = __builtin_amdgcn_rcpf(a);
   if (NS > 0 || n <= 64) {
@@ -86,7 +87,15 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
       const uint32_t key = (__float_as_uint(t) | (__float_as_uint(disc) & 0x80000000u));
       best = min(best, (key & ~imask) | (uint32_t)i);
     };
-    if constexpr (NS > 0) {
+    const uint32_t full = nn >= 32 ? 0xFFFFFFFFu : (1u << nn) - 1u;
+    uint32_t m = __builtin_amdgcn_readfirstlane(mask) & full;
+    if (NS > 0 && m != full) {
+      while (m) {
+        const int i = __builtin_ctz(m);
+        m &= m - 1u;
+        rank(sc.geom[i], i);
+      }
+    } else if constexpr (NS > 0) {
 #pragma unroll
       for (int i = 0; i < NS; i++) rank(sc.geom[i], i);
     } else {
@@ -151,6 +160,23 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
   F3 Lc = mk3(0, 0, 0), Ln = mk3(0, 0, 0), La = mk3(0, 0, 0);
   float Ld = 0.0f;
 
+  // the spheres this wave's primary rays can return at all (pt_footprint.h; the same exclusion the exact kernels use)
+  uint32_t prim_mask = 0xFFFFFFFFu;
+  if constexpr (NS > 0) {
+    if (a.spp >= 8) {
+      auto dir_at = [&](float sx, float sy) {
+        sx *= inv_h;
+        sy *= inv_w;
+        return lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
+      };
+      const uint32_t mine = active ? primary_candidates(sc, a.n_spheres, (float)row, (float)col, dir_at) : 0u;
+      uint32_t wm = 0u;
+#pragma unroll
+      for (int j = 0; j < NS; j++) wm |= (__builtin_amdgcn_ballot_w64(((mine >> j) & 1u) != 0u) != 0ull) ? (1u << j) : 0u;
+      prim_mask = wm;
+    }
+  }
+
   const int spp = active ? a.spp : 0;
   for (int i = 0; i < spp; i++) {  // :219
     rng.begin_sample((uint32_t)i);
@@ -173,7 +199,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
     auto bounce = [&](int n) -> bool {  // :155-196; false = the ray left the scene
       float t;
       int idx;
-      if (!nearest<NS>(sc, a.n_spheres, o, d, t, idx)) return false;
+      if (!nearest<NS>(sc, a.n_spheres, o, d, t, idx, n == 0 ? prim_mask : 0xFFFFFFFFu)) return false;
       const float4 g = sc.geom_lane(idx);
       F3 emis, scol;
       fetch_material(sc, idx, emis, scol);

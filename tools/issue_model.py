@@ -8,18 +8,21 @@ the kernel TOOK (kernel time x the clock GRBM_GUI_ACTIVE reports).
   f32 transcendental (rcp, rsq, sqrt)                                                                      8.1
   f64 transcendental                                                                                      16.2
 
-The mix is counted statically in the ISA of the hot path (the sample loop up to its first cold block -- the literal-loop
-fallbacks behind the rare redo branches); the count agrees with SQ_INSTS_VALU per sample to 0.3 %.
+Counts per class come from the profiler's own counters (SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 full-rate; *_F64 and CVT half-rate;
+TRANS_F32 / TRANS_F64).  The counters do not split the rest (integer ops, compares, selects, min/max, moves, bit ops) into
+full- and half-rate; that split is taken from the ISA of the kernel's hot path (the sample loop up to the literal-loop
+fallbacks, recognised by their FP64 division), where every instruction is classified by mnemonic.
 Usage: issue_model.py <isa.s> <kernel symbol substring> <profile json (profiles/rNN/tag.json)> <key in valu_roofline.json>"""
 import collections, json, os, sys
 
 isa, sym, prof, key = sys.argv[1:5]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COST = {"full": 2.2, "half": 4.1, "trans32": 8.1, "trans64": 16.2}
-FULL = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mov_b32",
-        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
+F32 = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32")
+FULL_OTHER = ("v_mov_b32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
 T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32")
 T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
+F64CVT = ("v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64", "v_cvt_")
 lines = open(isa).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and sym in l and l.split(";")[0].rstrip().endswith(":"))
 body = []
@@ -28,23 +31,36 @@ for l in lines[start + 1:]:
         break
     body.append(l)
 loop = next(i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l)      # the sample loop
-cold = next(i for i, l in enumerate(body) if i > loop and "Depth=2" in l)              # first literal-loop fallback block
-cnt = collections.Counter()
+cold = next(i for i, l in enumerate(body) if i > loop and "v_div_scale_f64" in l)   # first literal-loop fallback (FP64 division)
+while not body[cold].startswith(".LBB"):
+    cold -= 1
+rest = collections.Counter()
 for l in body[loop:cold]:
     t = l.strip().split()
     if not t or not t[0].startswith("v_"):
         continue
     op = t[0]
-    cnt["trans64" if op.startswith(T64) else "trans32" if op.startswith(T32) else "full" if op.startswith(FULL) else "half"] += 1
-need = sum(cnt[k] * COST[k] for k in cnt)
+    if op.startswith(F32 + T32 + T64 + F64CVT):
+        continue
+    rest["full" if op.startswith(FULL_OTHER) else "half"] += 1
+f_full = rest["full"] / max(rest["full"] + rest["half"], 1)
 d = json.load(open(os.path.join(root, prof)))
 c, v = d["pmc_per_launch_avg"], d["valu"]
 samples = d.get("samples_per_launch") or 2 ** 30
+per = lambda name: c[name] / (samples / 64)
+f32 = per("SQ_INSTS_VALU_ADD_F32") + per("SQ_INSTS_VALU_MUL_F32") + per("SQ_INSTS_VALU_FMA_F32")
+f64cvt = per("SQ_INSTS_VALU_ADD_F64") + per("SQ_INSTS_VALU_MUL_F64") + per("SQ_INSTS_VALU_FMA_F64") + per("SQ_INSTS_VALU_CVT")
+t32, t64 = per("SQ_INSTS_VALU_TRANS_F32"), per("SQ_INSTS_VALU_TRANS_F64")
+total = per("SQ_INSTS_VALU")
+other = total - f32 - f64cvt - t32 - t64
+mix = {"full": f32 + f_full * other, "half": f64cvt + (1.0 - f_full) * other, "trans32": t32, "trans64": t64}
+need = sum(mix[k] * COST[k] for k in mix)
 clock = c["GRBM_GUI_ACTIVE"] / 8 / (v["kernel_ms"] * 1e-3)  # the counter sums the 8 XCDs
 took = v["kernel_ms"] * 1e-3 * clock * 1024 / (samples / 64)
-rec = {"costs_cycles": COST, "static_mix_per_sample": dict(cnt), "static_valu_per_sample": sum(cnt.values()),
-       "measured_valu_per_sample": c["SQ_INSTS_VALU"] / (samples / 64), "needed_simd_cycles_per_sample": round(need, 1),
-       "clock_ghz": round(clock / 1e9, 4), "taken_simd_cycles_per_sample": round(took, 1), "frac": round(need / took, 4),
+rec = {"costs_cycles": COST, "mix_per_sample": {k: round(x, 1) for k, x in mix.items()}, "valu_per_sample": round(total, 1),
+       "unclassified_by_pmc_per_sample": round(other, 1), "full_rate_share_of_unclassified_from_isa": round(f_full, 3),
+       "needed_simd_cycles_per_sample": round(need, 1), "clock_ghz": round(clock / 1e9, 4),
+       "taken_simd_cycles_per_sample": round(took, 1), "frac": round(need / took, 4),
        "method": "tools/issue_model.py; costs from tools/ubench/valu_clock (profiles/r02/valu_issue_cost_ubench.txt)"}
 vp = os.path.join(root, "profiles", "valu_roofline.json")
 r = json.load(open(vp))
