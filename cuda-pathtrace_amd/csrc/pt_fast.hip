@@ -24,11 +24,7 @@ namespace fast {
 
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ F3 unit(F3 v) {
-#ifdef PT_FAST_DBG_NORMALIZE
-  const float k = 1.0f / sqrtf(dot3(v, v));
-#else
   const float k = __builtin_amdgcn_rsqf(dot3(v, v));
-#endif
   return mk3(v.x * k, v.y * k, v.z * k);
 }
 __device__ __forceinline__ float lum(F3 c) { return fmaf(0.2126f, c.x, fmaf(0.7152f, c.y, 0.0722f * c.z)); }
@@ -52,7 +48,8 @@ __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, cons
   // rounding (ulp 1024 at 1e10) moves the hit point by ~1e-3 units, and the image depends on it measurably: the
   // light is a 0.78-deep cap of a 600-radius sphere below the ceiling sphere, so its visible area follows the ceiling's
   // t to that precision.  Folding -r^2 into the fma chain is MORE accurate and shifts the mean radiance by 0.15 %
-  // (9 standard errors at 512^2 x 1024 spp) away from the reference's arithmetic -- measured, tools/fast_bias.py.
+  // (9 standard errors at 512^2 x 1024 spp) away from the reference's arithmetic -- measured with tools/fast_bias.py on builds that
+  // differed in this line only (exact sin/cos, exact normalisation and the FP64 sqrt(1 - r*r) changed nothing measurable).
   const float c = (off.x * off.x + off.y * off.y + off.z * off.z) - g.w;
   disc = fmaf(h, h, -a * c);                                                         // det / 4
   const float s = __builtin_amdgcn_sqrtf(disc);                                      // NaN when there is no real root
@@ -218,18 +215,8 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
       // getCosineWeightedNormal (:126-136) around the unit normal
       const F3 o1 = unit(ortho_vector(normal));
       const F3 o2 = cross(normal, o1);
-#ifdef PT_FAST_DBG_OM
-      const float ry = sqrtf(u_el), om = (float)sqrt(1.0 - (double)(ry * ry));
-#else
       const float ry = __builtin_amdgcn_sqrtf(u_el), om = __builtin_amdgcn_sqrtf(1.0f - u_el);
-#endif
-#ifdef PT_FAST_DBG_SINCOS
-      float sn0, cs0;
-      pt_sincos(u_az * 2.0f * 3.141592654f, sn0, cs0);
-      const float cs = cs0 * om, sn = sn0 * om;
-#else
       const float cs = __builtin_amdgcn_cosf(u_az) * om, sn = __builtin_amdgcn_sinf(u_az) * om;  // arguments in revolutions
-#endif
       d = unit(mk3(fmaf(o1.x, cs, fmaf(o2.x, sn, normal.x * ry)), fmaf(o1.y, cs, fmaf(o2.y, sn, normal.y * ry)),
                    fmaf(o1.z, cs, fmaf(o2.z, sn, normal.z * ry))));  // :180
       if (n == 0) {  // :187-195

@@ -131,6 +131,7 @@ struct pt_mgpu {
   int pending = 0;
   bool quit = false;
   bool init_phase = true;
+  bool failed = false;  // a frame timed out and a communicator was aborted: the object only accepts destroy from then on
   Job job;
 };
 
@@ -406,6 +407,7 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
   if (!d_out) return pt_fail(PT_EINVAL, "pt_mgpu_render: d_out is NULL");
   if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "pt_mgpu_render: bad scene (%d spheres)", n_spheres);
   if (!basis || !eye) return pt_fail(PT_EINVAL, "pt_mgpu_render: basis/eye is NULL");
+  if (m->failed) return pt_fail(PT_ECOMM, "pt_mgpu_render: an earlier frame timed out and its exchange was aborted; destroy and re-create");
   m->job.d_out = d_out;
   m->job.d_spheres = d_spheres;
   m->job.n_spheres = n_spheres;
@@ -413,6 +415,7 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
   memcpy(m->job.eye, eye, sizeof(m->job.eye));
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = run_all(m, "pt_mgpu_render");
+  if (rc == PT_ETIMEOUT) m->failed = true;
   if (ms_out) *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Image means of the fast mode vs the exact kernel at 1024 x 1024 x 128 spp for alternative builds (bias hunting).
+"""Image means of the fast mode vs the exact kernel at 1024 x 1024 x 128 spp for alternative builds (bias hunting: build
+variants of pt_fast.hip with tools/build_alt.sh and compare their means; this is how the rounding order of c was found to matter).
 Usage: fast_bias.py name...   (cuda-pathtrace_amd/alt/<name>/libptcore.so; "main" = the product library)"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# After `gpurun -- bash tools/profile_all.sh` has brought gpurun_out/prof_* back: summarise into profiles/<round>/ and rebuild
+# profiles/hbm_traffic.json + profiles/valu_roofline.json (fingerprinted; bench.py ignores them for any other build).
+# Usage: tools/refresh_profiles.sh [round=r02]
+set -e
+cd "$(dirname "$0")/.."
+R=${1:-r02}
+python3 tools/summarise_profile.py cfg2_xorwow $R > /dev/null
+python3 tools/summarise_profile.py cfg2_philox $R > /dev/null
+python3 tools/summarise_profile.py cfg4_grid $R > /dev/null
+rm -f profiles/hbm_traffic.json profiles/valu_roofline.json
+python3 tools/update_roofline_json.py cfg2_xorwow $R cfg2_xorwow_v6
+python3 tools/update_roofline_json.py cfg2_philox $R cfg2_philox_v8
+bash tools/isa.sh /tmp/pt_kernel_final.s
+python3 tools/issue_model.py /tmp/pt_kernel_final.s pixel_kernelILi0ELi6ELb0ELb1 profiles/$R/cfg2_xorwow.json cfg2_xorwow_v6 | cut -c1-400
+cp gpurun_out/config_times_vauto.json profiles/$R/config_times_auto.json
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import __graft_entry__ as ge
+fp = ge.load_package().build_fingerprint()
+rec = json.load(open("profiles/valu_roofline.json"))["cfg2_xorwow_v6"]
+print("library", fp, "profile", rec["fingerprint"], "OK" if fp == rec["fingerprint"] else "STALE: rebuild / re-profile")
+PY
