@@ -43,6 +43,9 @@ namespace pt {
 #define PT_GRID_CELLS_PER_SPHERE 2.0f
 #endif
 constexpr int kGridMaxCells = PT_GRID_MAX_CELLS;
+#ifndef PT_GRID_TESTS_PER_TRIP
+#define PT_GRID_TESTS_PER_TRIP 3
+#endif
 #ifndef PT_GRID_MAX_ITEMS
 #define PT_GRID_MAX_ITEMS 8192
 #endif
@@ -556,17 +559,29 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
     PT_STAT(1, 1);
     PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(testing)));
     if (testing) {
-      // Two registered spheres per trip where the list has two left: the loop is latency-bound (dependent LDS reads, a
-      // 25-deep dependency chain per test), so the second test's chain runs in the shadow of the first (-9 %).
       // (Measured and dropped: requesting the NEXT trip's two indices before the tests, to take one LDS latency off the
       // chain -- 3 % slower: the extra selects and the stale-list check cost more than the latency six waves already hide.)
+      // Up to three registered spheres per trip, as many as the list has left: index and geometry reads of all of them are
+      // issued first, so the tests' dependency chains overlap (the loop is latency-bound).  1 -> 2 per trip: -9 %, 2 -> 3: -3 %.
       const bool two = k0 + 1u < k1;
+#if PT_GRID_TESTS_PER_TRIP >= 3
+      const bool three = k0 + 2u < k1;
+      const int i = (int)G.items[k0];
+      const int j = (int)G.items[two ? k0 + 1u : k0];
+      const int l = (int)G.items[three ? k0 + 2u : k0];
+      const float4 gi = G.geom[i], gj = G.geom[j], gl = G.geom[l];
+      k0 += three ? 3u : (two ? 2u : 1u);
+      near2_test(s, gi, i, o, d, a4, Tlim_hi);
+      if (two) near2_test(s, gj, j, o, d, a4, Tlim_hi);
+      if (three) near2_test(s, gl, l, o, d, a4, Tlim_hi);
+#else
       const int i = (int)G.items[k0];
       const int j = (int)G.items[two ? k0 + 1u : k0];
       const float4 gi = G.geom[i], gj = G.geom[j];
       k0 += two ? 2u : 1u;
       near2_test(s, gi, i, o, d, a4, Tlim_hi);
       if (two) near2_test(s, gj, j, o, d, a4, Tlim_hi);
+#endif
     }
   }
   const bool has = s.T1 < INF;
