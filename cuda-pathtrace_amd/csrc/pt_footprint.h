@@ -40,6 +40,17 @@
 
 namespace pt {
 
+// The two constants of the argument above.  PT_FOOTPRINT_MUTANT (never defined in a shipped build) makes one of them
+// deliberately UNSOUND -- footprint radius x 0.3, or a wall counted as farther when it is 3 % NEARER -- to show that
+// tools/footprint_soak.py notices (profiles/r02/footprint_mutants.txt).
+#if defined(PT_FOOTPRINT_MUTANT) && PT_FOOTPRINT_MUTANT == 1
+constexpr float kFootprintRadiusFactor = 0.3f, kFootprintMargin = 1.07f;
+#elif defined(PT_FOOTPRINT_MUTANT) && PT_FOOTPRINT_MUTANT == 2
+constexpr float kFootprintRadiusFactor = 1.05f, kFootprintMargin = 0.93f;
+#else
+constexpr float kFootprintRadiusFactor = 1.05f, kFootprintMargin = 1.07f;
+#endif
+
 // dir_at(sx, sy): the primary direction for screen position (sx, sy) in PIXEL units, by the kernel's own formula
 template <typename DirFn>
 __device__ __forceinline__ uint32_t primary_candidates(const SceneLds& sc, int n, float row, float col, DirFn dir_at) {
@@ -57,17 +68,13 @@ __device__ __forceinline__ uint32_t primary_candidates(const SceneLds& sc, int n
   }
   dmax *= 1.000001f;
   const float dmin = (lc - dev) * 0.999999f;
-#ifdef PT_FOOTPRINT_MUTANT  // never defined in a shipped build: deliberately UNSOUND variants, to show that the soak has teeth
-  const float rho = (PT_FOOTPRINT_MUTANT == 1 ? 0.3f : 1.05f) * dev / lc + 1e-6f;
-#else
-  const float rho = 1.05f * dev / lc + 1e-6f;  // >= asin(dev / lc) for dev / lc <= 0.3
-#endif
+  const float rho = kFootprintRadiusFactor * dev / lc + 1e-6f;  // 1.05 dev / lc >= asin(dev / lc) for dev / lc <= 0.3
   if (!(rho <= 0.00390625f) || !(dmin > 0.0f) || !(lc > 0.0f)) return all;  // NaN, degenerate or coarse footprint: keep all
   const F3 u = dc * (1.0f / lc);
 
   // pass 1: the reference wall W
   float Uw = __builtin_inff();
-  float dist_c[16], cosphi[16];
+  float dist_c[16];
   bool tame[16];
   for (int j = 0; j < n; j++) {
     const float4 e = sc.eyeg[j];
@@ -76,7 +83,6 @@ __device__ __forceinline__ uint32_t primary_candidates(const SceneLds& sc, int n
     const float o2 = dot(off, off), c = e.w, hu = dot(u, off);
     tame[j] = false;
     dist_c[j] = 0.0f;
-    cosphi[j] = 0.0f;
     if (c <= -o2 * 0.000244140625f) {  // eye robustly inside
       const float sq = sqrtf(hu * hu - c);
       const float dist = hu > 0.0f ? (-c) / (sq + hu) : (sq - hu);
@@ -84,7 +90,6 @@ __device__ __forceinline__ uint32_t primary_candidates(const SceneLds& sc, int n
       const bool ok = (cp >= 100.0f * rho) && (rho * (1.0f + 2.5f * dist / (r * cp)) <= 0.5f * cp) && (dist > 0.0f);
       tame[j] = ok;
       dist_c[j] = dist;
-      cosphi[j] = cp;
       const float U = dmax * 1.0203f * dist;
       if (ok && (1.0203f * dist / dmin < 900000.0f) && U < Uw) Uw = U;
     }
@@ -102,23 +107,12 @@ __device__ __forceinline__ uint32_t primary_candidates(const SceneLds& sc, int n
       const float cosc = fabsf(hu) / lo + rho;
       drop = drop | (cosc * cosc <= (c / o2) * 0.999755859375f);                     // (A) missed
       drop = drop | (hu > rho * lo * 1.000001f);                                     // (B) behind
-#if defined(PT_FOOTPRINT_MUTANT) && PT_FOOTPRINT_MUTANT == 2
-      const float kMargin = 0.93f;
-#else
-      const float kMargin = 1.07f;
-#endif
-      drop = drop | (dmin * (lo - r) * 0.9990234375f >= kMargin * Uw);               // (C) farther than W
+      drop = drop | (dmin * (lo - r) * 0.9990234375f >= kFootprintMargin * Uw);      // (C) farther than W
     } else if (tame[j]) {
-#if defined(PT_FOOTPRINT_MUTANT) && PT_FOOTPRINT_MUTANT == 2
-      const float kMargin = 0.93f;
-#else
-      const float kMargin = 1.07f;
-#endif
-      drop = drop | (dmin * dist_c[j] * (1.0f / 1.0203f) >= kMargin * Uw);           // (C)
+      drop = drop | (dmin * dist_c[j] * (1.0f / 1.0203f) >= kFootprintMargin * Uw);  // (C)
     }
     keep |= drop ? 0u : (1u << j);
   }
-  (void)cosphi;
   return keep;
 }
 
