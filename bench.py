@@ -170,6 +170,12 @@ def main():
     if args.gpus > 1 and args.engine == "dist" and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))  # before anything here touches the GPU
 
+    # stdout carries ONE JSON line and nothing else: libraries that print to file descriptor 1 on their own (RCCL writes a
+    # version banner there when a communicator is created) are pointed at stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -400,7 +406,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(oracle, cfg, spheres, basis, args.cpu_rows)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if use_dist:
         dist.barrier()
