@@ -360,6 +360,20 @@ __device__ __forceinline__ float inv_sqrt_spec_nb(float x, bool& bad) {
 
 __device__ __forceinline__ F3 normalize_nb(F3 v, bool& bad) { return v * inv_sqrt_spec_nb(dot(v, v), bad); }
 
+// normalize() of a vector that is ALREADY of unit length up to rounding (the second normalisation of the shading normal,
+// the cross product of two orthogonal unit vectors, the cosine-weighted combination: pathtrace.cu:127,129,180).  Its squared
+// length is within a few ulps of 1, so 1.0f / sqrtf(x) takes one of a handful of values: they are tabulated once per workgroup
+// with the LITERAL expression (kUnitTab entries for the bit patterns 0x3F800000 - 16 ... + 16, SceneLds::inv1) and looked up
+// by the integer distance of x's bits from 1.0f -- an LDS read instead of v_rsq_f32 and its correction steps.  Anything
+// farther from 1 raises the redo flag like every other unverified input.
+constexpr int kUnitTabHalf = 16, kUnitTabSize = 64;
+__device__ __forceinline__ F3 normalize_unit_nb(F3 v, const float* __restrict__ tab, bool& bad) {
+  const float x = dot(v, v);
+  const uint32_t k = __float_as_uint(x) - (0x3F800000u - (uint32_t)kUnitTabHalf);
+  bad = bad | (k > 2u * (uint32_t)kUnitTabHalf);
+  return v * tab[k & (uint32_t)(kUnitTabSize - 1)];
+}
+
 __device__ __forceinline__ double sqrt_cr_nb(double x, bool& bad) {
   const uint32_t hi = (uint32_t)__double2hiint(x);
   bad = bad | ((hi - (423u << 20)) >= (1200u << 20));  // sign set, exponent outside 2^-600..2^600, inf, NaN
@@ -419,8 +433,10 @@ struct BounceGeom {
   F3 o, d;    // next ray
 };
 
-template <bool FAST>
-__device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 centre, float u_az, float u_el, bool& bad) {
+// TAB: unit_tab = SceneLds::inv1, the LDS table for normalize_unit_nb (scenes that are not staged have none: the general sequence)
+template <bool FAST, bool TAB = false>
+__device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 centre, float u_az, float u_el, bool& bad,
+                                                      const float* unit_tab = nullptr) {
   BounceGeom out;
   F3 pos = o + d * t;
   F3 normal = pos - centre;
@@ -432,9 +448,9 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
   F3 dir, o1, o2;
   float ry, oneminus;
   if constexpr (FAST) {
-    dir = normalize_nb(normal, bad);
+    if constexpr (TAB) dir = normalize_unit_nb(normal, unit_tab, bad); else dir = normalize_nb(normal, bad);
     o1 = normalize_nb(ortho_vector(dir), bad);
-    o2 = normalize_nb(cross(dir, o1), bad);
+    if constexpr (TAB) o2 = normalize_unit_nb(cross(dir, o1), unit_tab, bad); else o2 = normalize_nb(cross(dir, o1), bad);
     ry = sqrt_cr_f32_nb(u_el, bad);
     oneminus = (float)sqrt_cr_nb(1.0 - (double)(ry * ry), bad);
   } else {
@@ -451,7 +467,9 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
   F3 b = o2 * (sn * oneminus);
   F3 c = dir * ry;
   F3 nd = (a + b) + c;
-  if constexpr (FAST) out.d = normalize_nb(nd, bad); else out.d = normalize(nd);
+  if constexpr (FAST && TAB) out.d = normalize_unit_nb(nd, unit_tab, bad);
+  else if constexpr (FAST) out.d = normalize_nb(nd, bad);
+  else out.d = normalize(nd);
   return out;
 }
 
