@@ -255,17 +255,38 @@ struct RayConst {
   double rden;  // ~1/den, <= 1 ulp
 };
 
+// ~1/den to <= 1 ulp: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double ray_const_rden(double den) {
+  double r = __builtin_amdgcn_rcp(den);
+  double e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-den, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 __device__ __forceinline__ RayConst make_ray_const(F3 d) {
   RayConst rc;
   rc.a = dot(d, d);
   rc.a4 = 4.0f * rc.a;
   rc.a4d = 4.0 * (double)rc.a;
   rc.den = 2.0 * (double)rc.a;
-  double r = __builtin_amdgcn_rcp(rc.den);
-  double e = __builtin_fma(-rc.den, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-rc.den, r, 1.0);
-  rc.rden = __builtin_fma(r, e, r);
+  rc.rden = ray_const_rden(rc.den);
+  return rc;
+}
+
+// make_ray_const for a direction that is of unit length up to rounding (every ray but the primary one: bounce_geometry
+// normalises it): a = dot(d, d) is within a few ulps of 1, so the refined reciprocal of 2a is one of a handful of doubles,
+// tabulated once per workgroup by make_ray_const itself (SceneLds::rden1, same index as normalize_unit_nb's table).  Saves
+// the v_rcp_f64 and its four refinement steps per bounce.  Any other a takes the general routine.
+__device__ __forceinline__ RayConst make_ray_const_unit(F3 d, const double* __restrict__ tab) {
+  RayConst rc;
+  rc.a = dot(d, d);
+  const uint32_t k = __float_as_uint(rc.a) - (0x3F800000u - 16u);
+  if (__builtin_expect(k > 32u, 0)) return make_ray_const(d);
+  rc.a4 = 4.0f * rc.a;
+  rc.a4d = 4.0 * (double)rc.a;
+  rc.den = 2.0 * (double)rc.a;
+  rc.rden = tab[k & 63u];
   return rc;
 }
 

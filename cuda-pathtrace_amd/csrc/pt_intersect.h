@@ -449,7 +449,8 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
 
 template <int VAR, bool PRIMARY = false>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
-  const RayConst rc = make_ray_const(d);
+  // every ray but the primary one has a unit direction: its constants come from the workgroup's table (any other a: general routine)
+  const RayConst rc = (VAR >= 6 && !PRIMARY && !sc.lean) ? make_ray_const_unit(d, sc.rden1) : make_ray_const(d);
   if constexpr (VAR >= 5) {
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
@@ -475,7 +476,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   ScreenState st[P];
 #pragma unroll
   for (int p = 0; p < P; p++) {
-    rc[p] = make_ray_const(d[p]);
+    rc[p] = (!PRIMARY && !sc.lean) ? make_ray_const_unit(d[p], sc.rden1) : make_ray_const(d[p]);
     st[p] = ScreenState{0xFFFFFFFFu, 0xFFFFFFFFu, false};
     hit[p] = false;
   }

@@ -474,7 +474,7 @@ static inline bool lds_lean(int n, int variant) {
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
   if (lds_lean(n, variant)) return 0;  // the lean builds read the caller's array directly
-  return (size_t)n * 4 + pt::kUnitTabSize / 4 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image, the unit-length table
+  return (size_t)n * 4 + (pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2) + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image, the unit-length table
 }
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
@@ -560,7 +560,7 @@ int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
   if (variant == 6 || variant == 8 || variant == 10 || variant == 11) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
-  const size_t fixed = tail + (pt::kUnitTabSize / 4) * sizeof(float4);
+  const size_t fixed = tail + ((pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2)) * sizeof(float4);
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - fixed - 2 * sizeof(float4)) / (5 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
 }
