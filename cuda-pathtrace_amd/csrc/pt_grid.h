@@ -387,14 +387,23 @@ __device__ unsigned long long g_grid_stats[8];
 #else
 #define PT_STAT(i, v) do { } while (0)
 #endif
+#ifdef PT_GRID_STATS_AMBIG
+#define PT_STATW(i, v) do { } while (0)   // the walk's own counters make room for the reasons
+#else
+#define PT_STATW(i, v) PT_STAT(i, v)
+#endif
 struct Near2 {
   float T1, T2;  // two smallest estimates of 2a*t
   int i1;
-  bool unsure;
 };
 
-// one sphere for one lane: the float part and the estimate of intersect_scene_screened_large, predicated
-__device__ __forceinline__ void near2_test(Near2& s, const float4 g, int i, F3 o, F3 d, float a4, float Tlim_hi) {
+// One sphere for one lane: the float part and the estimate of intersect_scene_screened_large, predicated.
+// Returns "doubt": the estimate cannot be trusted (the exact discriminant is within the rounding error of the reference's
+// float `det`, whose sign decides hit or miss; or an operand is zero / not finite).  Such a sphere has NOT been entered:
+// near2_exact() decides it with the reference's own expression.  (Until round 2 a doubt anywhere sent the lane to the
+// literal loop over ALL spheres of the scene: 5e-4 of the lanes per bounce at 1000 spheres -- one lane in 2.4 % of the
+// wave-bounces -- and with it a quarter of the frame time in the closed and 40 % in the open configuration.)
+__device__ __forceinline__ bool near2_test(Near2& s, const float4 g, int i, F3 o, F3 d, float a4, float Tlim_hi) {
   const float INF = __builtin_inff();
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
   const float b = 2.0f * dot(d, off);
@@ -413,13 +422,41 @@ __device__ __forceinline__ void near2_test(Near2& s, const float4 g, int i, F3 o
   // the root the reference returns: origin inside (c < 0) the larger, outside the smaller (screen_sphere, pt_intersect.h)
   const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));
   const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
-  const bool ok = cand & ((int)__float_as_uint(T) >= 0) & (T < Tlim_hi);
   const float m = fabsf(a4c) * 4.7683716e-07f;  // 2^-21 |4ac|
-  s.unsure = s.unsure | (cand & !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m));
+  const bool sure = fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m;
+  const bool ok = cand & sure & ((int)__float_as_uint(T) >= 0) & (T < Tlim_hi);
   const float Te = ok ? T : INF;
   s.i1 = Te < s.T1 ? i : s.i1;
   s.T2 = __builtin_amdgcn_fmed3f(s.T1, s.T2, Te);  // the second smallest of {T1, T2, Te} (T1 <= T2 always)
   s.T1 = fminf(s.T1, Te);
+  return cand & !sure;
+}
+
+// a sphere near2_test had doubts about: the reference's own test (pathtrace.cu:72-91, FP64 sqrt and divides) and its
+// acceptance rule (:99: t > 0; the upper limit is applied to the winner).  2a*t is entered in place of the estimate -- it
+// is the quantity the estimates approximate, 2^-24 away from it, far inside the margins the ranking keeps.
+__device__ __forceinline__ void near2_exact(Near2& s, const float4 g, int i, F3 o, F3 d, float a, float Tlim_hi) {
+  const float INF = __builtin_inff();
+  float t = 0.0f;
+  const bool h = intersect_sphere(o, d, a, g, t);
+  const float T = (2.0f * a) * t;
+  const bool ok = h & (t > 0.0f) & (T < Tlim_hi) & !((i == s.i1) & (s.T1 < INF));
+  const float Te = ok ? T : INF;
+  s.i1 = Te < s.T1 ? i : s.i1;
+  s.T2 = __builtin_amdgcn_fmed3f(s.T1, s.T2, Te);
+  s.T1 = fminf(s.T1, Te);
+}
+
+// up to three doubted spheres of one trip (bit k of `doubts`: the k-th of them), one copy of the FP64 test
+__device__ __forceinline__ void near2_resolve(Near2& s, uint32_t doubts, const float4 g0, int i0, const float4 g1, int i1,
+                                              const float4 g2, int i2, F3 o, F3 d, float a, float Tlim_hi) {
+  while (doubts != 0u) {
+    const bool k0 = (doubts & 1u) != 0u, k1 = !k0 & ((doubts & 2u) != 0u);
+    const float4 g = k0 ? g0 : (k1 ? g1 : g2);
+    const int i = k0 ? i0 : (k1 ? i1 : i2);
+    near2_exact(s, g, i, o, d, a, Tlim_hi);
+    doubts &= k0 ? ~1u : (k1 ? ~2u : ~4u);
+  }
 }
 
 // Nearest hit through the grid.  Loop shape ("test-major"): every trip of the main loop tests ONE registered sphere for
@@ -432,13 +469,32 @@ __device__ __forceinline__ void near2_test(Near2& s, const float4 g, int i, F3 o
 // the three "cells left before the box ends" counters sit in one register, 10 bits each with a guard bit on top of each
 // field (a decrement that clears a guard bit has left the box), so no per-axis cell coordinates or bounds tests are kept.
 // (The ray's FP64 constants are formed AFTER the walk: six registers the loop does not have to carry.)
-__device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
-                                                     float& t_hit, int& idx) {
+//
+// The walk is three pieces -- grid_begin (the spheres outside the grid, the clip against the box, the DDA state),
+// grid_trips (the loop) and grid_end (the exact step on the winner) -- so that variant 12 can keep a lane's GridWalk alive
+// across loop iterations of the pixel kernel; variant 11 calls them back to back.
+struct GridWalk {
+  Near2 s;
+  float a;                         // dot(d, d)
+  float tmax0, tmax1, tmax2, tdel0, tdel1, tdel2;
+  int cidx;
+  int cs0, cs1, cs2;               // what one step along the axis adds to the linear cell index (three scalars, NOT an array:
+                                   // a select between array elements becomes an indexed load from scratch memory)
+  uint32_t left;                   // per axis: cells left before the box ends, bits 10k..10k+8, guard bit 10k+9
+  uint32_t k0, k1;                 // the list of the cell being tested
+  uint32_t n0, n1;                 // the list of the NEXT cell, fetched ahead of need (valid while have_next)
+  bool have_next;
+  bool walking;                    // the DDA can still move on: neither stopped nor out of the box
+  __device__ __forceinline__ bool busy() const { return (k0 < k1) | have_next | walking; }
+};
+
+__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a) {
   const float INF = __builtin_inff();
   const float two_a = 2.0f * a, a4 = 4.0f * a;
   const float Tlim = 1000000.0f * two_a;
   const float Tlim_hi = Tlim * 1.0000153f;
-  Near2 s{INF, INF, 0, false};
+  w.a = a;
+  w.s = Near2{INF, INF, 0};
   // spheres outside the grid (walls, very large or very small ones): every lane tests all of them
   {
     const int nb = (int)G.h.n_big;  // wave-uniform
@@ -446,12 +502,14 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
     for (; k + 2 <= nb; k += 2) {  // in pairs: two independent dependency chains per trip
       const int i = (int)G.big[k], j = (int)G.big[k + 1];
       const float4 gi = G.geom[i], gj = G.geom[j];
-      near2_test(s, gi, i, o, d, a4, Tlim_hi);
-      near2_test(s, gj, j, o, d, a4, Tlim_hi);
+      const bool di = near2_test(w.s, gi, i, o, d, a4, Tlim_hi);
+      const bool dj = near2_test(w.s, gj, j, o, d, a4, Tlim_hi);
+      if (__builtin_expect(di | dj, 0)) near2_resolve(w.s, (di ? 1u : 0u) | (dj ? 2u : 0u), gi, i, gj, j, gj, j, o, d, a, Tlim_hi);
     }
     if (k < nb) {
       const int i = (int)G.big[k];
-      near2_test(s, G.geom[i], i, o, d, a4, Tlim_hi);
+      const float4 gi = G.geom[i];
+      if (__builtin_expect(near2_test(w.s, gi, i, o, d, a4, Tlim_hi), 0)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);
     }
   }
   // clip against the grid box
@@ -477,11 +535,10 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
   const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(a);
   bool active = (t_in <= t_out + slack_t) & (t_in * two_a < Tlim_hi);
   // entry cell and DDA state
-  float tmax0 = INF, tmax1 = INF, tmax2 = INF, tdel0 = INF, tdel1 = INF, tdel2 = INF;
+  w.tmax0 = INF, w.tmax1 = INF, w.tmax2 = INF, w.tdel0 = INF, w.tdel1 = INF, w.tdel2 = INF;
   int cidx = 0;
-  int cs0 = 0, cs1 = 0, cs2 = 0;   // what one step along the axis adds to the linear cell index (three scalars, NOT an array:
-                                   // a select between array elements becomes an indexed load from scratch memory)
-  uint32_t left = 0x20080200u;     // per axis: cells left before the box ends, bits 10k..10k+8, guard bit 10k+9
+  w.cs0 = 0, w.cs1 = 0, w.cs2 = 0;
+  uint32_t left = 0x20080200u;
   const int stride[3] = {1, dims[0], dims[0] * dims[1]};
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -492,32 +549,50 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
     const float bnd = gmin[k] + (float)(ci + (fwd ? 1 : 0)) * G.h.cs;
     const float tm = par[k] ? INF : (bnd - oo[k]) * inv[k];   // a parallel axis is never the exit face
     const float td = par[k] ? INF : G.h.cs * fabsf(inv[k]);
-    if (k == 0) { tmax0 = tm; tdel0 = td; }
-    if (k == 1) { tmax1 = tm; tdel1 = td; }
-    if (k == 2) { tmax2 = tm; tdel2 = td; }
+    if (k == 0) { w.tmax0 = tm; w.tdel0 = td; }
+    if (k == 1) { w.tmax1 = tm; w.tdel1 = td; }
+    if (k == 2) { w.tmax2 = tm; w.tdel2 = td; }
     cidx += ci * stride[k];
     const int sk = fwd ? stride[k] : -stride[k];
-    if (k == 0) cs0 = sk;
-    if (k == 1) cs1 = sk;
-    if (k == 2) cs2 = sk;
+    if (k == 0) w.cs0 = sk;
+    if (k == 1) w.cs1 = sk;
+    if (k == 2) w.cs2 = sk;
     left |= (uint32_t)(fwd ? dims[k] - 1 - ci : ci) << (10 * k);
   }
-  // (Written without a lambda on purpose: captured by reference, cs0..2 stayed addressable and the step's select became a
-  // select of ADDRESSES followed by a load from scratch memory -- hundreds of cycles in the innermost loop.)
   cidx = active ? cidx : 0;
-  uint32_t k0 = G.cell_start[cidx], k1 = G.cell_start[cidx + 1];  // the list of the cell being tested
-  if (!active) k1 = k0;
-  uint32_t n0 = 0, n1 = 0;  // the list of the NEXT cell, fetched ahead of need (valid while have_next)
-  bool have_next = false;
+  w.cidx = cidx;
+  w.left = left;
+  w.k0 = G.cell_start[cidx], w.k1 = G.cell_start[cidx + 1];
+  if (!active) w.k1 = w.k0;
+  w.n0 = 0, w.n1 = 0;
+  w.have_next = false;
 #ifdef PT_TIMING_ONLY_NO_WALK   // never defined in a shipped build: what the kernel costs without the grid walk
   active = false;
-  k1 = k0;
+  w.k1 = w.k0;
 #endif
-  bool walking = active;    // the DDA can still move on: neither stopped nor out of the box
-  // (Written without a lambda on purpose: captured by reference, cs0..2 stayed addressable and the step's select became a
-  // select of ADDRESSES followed by a load from scratch memory -- hundreds of cycles in the innermost loop.)
+  w.walking = active;
   PT_STAT(0, 1);
   PT_STAT(5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+}
+
+// The loop.  in_walk: the lane has a walk to advance (variant 11: every lane that called).  PARK (variant 12): leave as soon
+// as `park` or more of the wave's lanes have nothing left to do -- their owner re-arms them with the next ray and comes back;
+// PARK = false runs until no lane has anything left.
+template <bool PARK>
+__device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 o, F3 d, bool in_walk, bool alive, int park) {
+  const float two_a = 2.0f * walk.a, a4 = 4.0f * walk.a;
+  const float Tlim_hi = 1000000.0f * two_a * 1.0000153f;
+  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
+  // Every field in a local of its own, written back at the end: read through the reference, the step's
+  // `a0 ? cs0 : (a1 ? cs1 : cs2)` becomes a select of ADDRESSES followed by a load from scratch memory (the struct is
+  // scalarised only after inlining, the select is rewritten before) -- hundreds of cycles in the innermost loop.
+  Near2 s = walk.s;
+  float tmax0 = walk.tmax0, tmax1 = walk.tmax1, tmax2 = walk.tmax2;
+  const float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
+  int cidx = walk.cidx;
+  const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
+  uint32_t left = walk.left, k0 = walk.k0, k1 = walk.k1, n0 = walk.n0, n1 = walk.n1;
+  bool have_next = walk.have_next, walking = walk.walking;
   for (;;) {
     // Stepping is done one cell AHEAD and for the whole wave at once: a round is triggered only when some lane has used
     // up its list and has no next one in hand, and in that round EVERY lane without a next list takes its step.  (One
@@ -529,11 +604,11 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
       k0 = swap ? n0 : k0;
       k1 = swap ? n1 : k1;
       have_next = have_next & !swap;
-      const bool starving = walking & (k0 >= k1);  // have_next is false here for such a lane
+      const bool starving = in_walk & walking & (k0 >= k1);  // have_next is false here for such a lane
       if (__builtin_amdgcn_ballot_w64(starving) == 0) break;
-      const bool step = walking & !have_next;
-      PT_STAT(3, 1);
-      PT_STAT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(step)));
+      const bool step = in_walk & walking & !have_next;
+      PT_STATW(3, 1);
+      PT_STATW(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(step)));
       if (step) {
         const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
         const float reach = (t_exit - slack_t) * two_a;
@@ -554,10 +629,15 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
         }
       }
     }
-    const bool testing = k0 < k1;
-    if (__builtin_amdgcn_ballot_w64(testing) == 0) break;  // no lane has a list left, and none can get one
-    PT_STAT(1, 1);
-    PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(testing)));
+    const bool testing = in_walk & (k0 < k1);
+    const uint64_t testing_mask = __builtin_amdgcn_ballot_w64(testing);
+    if (testing_mask == 0) break;  // no lane has a list left, and none can get one
+    if constexpr (PARK) {
+      // lanes of unfinished pixels with nothing left to do here, against the parking threshold
+      if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive & !(in_walk & ((k0 < k1) | have_next | walking)))) >= park) break;
+    }
+    PT_STATW(1, 1);
+    PT_STATW(2, __builtin_popcountll(testing_mask));
     if (testing) {
       // (Measured and dropped: requesting the NEXT trip's two indices before the tests, to take one LDS latency off the
       // chain -- 3 % slower: the extra selects and the stale-list check cost more than the latency six waves already hide.)
@@ -571,33 +651,73 @@ __device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const G
       const int l = (int)G.items[three ? k0 + 2u : k0];
       const float4 gi = G.geom[i], gj = G.geom[j], gl = G.geom[l];
       k0 += three ? 3u : (two ? 2u : 1u);
-      near2_test(s, gi, i, o, d, a4, Tlim_hi);
-      if (two) near2_test(s, gj, j, o, d, a4, Tlim_hi);
-      if (three) near2_test(s, gl, l, o, d, a4, Tlim_hi);
+      uint32_t doubts = near2_test(s, gi, i, o, d, a4, Tlim_hi) ? 1u : 0u;
+      if (two) doubts |= near2_test(s, gj, j, o, d, a4, Tlim_hi) ? 2u : 0u;
+      if (three) doubts |= near2_test(s, gl, l, o, d, a4, Tlim_hi) ? 4u : 0u;
+      if (__builtin_expect(doubts != 0u, 0)) near2_resolve(s, doubts, gi, i, gj, j, gl, l, o, d, walk.a, Tlim_hi);
 #else
       const int i = (int)G.items[k0];
       const int j = (int)G.items[two ? k0 + 1u : k0];
       const float4 gi = G.geom[i], gj = G.geom[j];
       k0 += two ? 2u : 1u;
-      near2_test(s, gi, i, o, d, a4, Tlim_hi);
-      if (two) near2_test(s, gj, j, o, d, a4, Tlim_hi);
+      uint32_t doubts = near2_test(s, gi, i, o, d, a4, Tlim_hi) ? 1u : 0u;
+      if (two) doubts |= near2_test(s, gj, j, o, d, a4, Tlim_hi) ? 2u : 0u;
+      if (__builtin_expect(doubts != 0u, 0)) near2_resolve(s, doubts, gi, i, gj, j, gj, j, o, d, walk.a, Tlim_hi);
 #endif
     }
   }
+  walk.s = s;
+  walk.tmax0 = tmax0, walk.tmax1 = tmax1, walk.tmax2 = tmax2;
+  walk.cidx = cidx;
+  walk.left = left, walk.k0 = k0, walk.k1 = k1, walk.n0 = n0, walk.n1 = n1;
+  walk.have_next = have_next, walk.walking = walking;
+}
+
+__device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d,
+                                         float& t_hit, int& idx) {
+  const float INF = __builtin_inff();
+  const float Tlim = 1000000.0f * (2.0f * w.a);
+  const Near2& s = w.s;
   const bool has = s.T1 < INF;
-  bool ambiguous = s.unsure | (has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f)));
+  bool ambiguous = has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f));
   float t;
   bool bad = false;
   const RayConst rc = make_ray_const(d);
-  const bool real = intersect_sphere_nb(o, d, rc, G.geom[s.i1], t, bad);
+  const float4 gw = G.geom[s.i1];
+  bool real = intersect_sphere_nb(o, d, rc, gw, t, bad);
+  // the cheap sequences met an input outside their verified domain: the literal test, for the winner alone
+  if (__builtin_expect(has & bad, 0)) real = intersect_sphere(o, d, rc.a, gw, t);
   const bool good = real & (t > 0.0f) & (t < 1000000.0f);
-  ambiguous = ambiguous | (has & (bad | !good));
+  ambiguous = ambiguous | (has & !good);
   t_hit = t;
   idx = s.i1;
   bool hit = has & good;
   PT_STAT(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(ambiguous)));
+#ifdef PT_GRID_STATS_AMBIG  // why lanes are ambiguous (tools/grid_stats.py ambig): slots 1-4 and 7 re-used
+  PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & (s.T2 <= s.T1 * 1.0000038f))));
+  PT_STAT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & (s.T1 >= Tlim * 0.99998f))));
+  PT_STAT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & bad)));
+  PT_STAT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & !good)));
+#endif
+#ifndef PT_TIMING_ONLY_NO_AMBIG  // never defined in a shipped build: what the literal redo of ambiguous lanes costs
   if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+#endif
   return hit;
+}
+
+__device__ __forceinline__ bool intersect_scene_grid(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
+                                                     float& t_hit, int& idx) {
+  GridWalk w;
+  grid_begin(w, G, o, d, a);
+  grid_trips<false>(w, G, o, d, true, true, 0);
+  return grid_end(w, sc, G, n, o, d, t_hit, idx);
+}
+
+// is this ray one the grid may be used for?  (finite, and starting within the admission radius the registration margins assume)
+__device__ __forceinline__ bool grid_admits(const GridLds& G, F3 o, F3 d, float a) {
+  const F3 oc = mk3(o.x - G.h.cx, o.y - G.h.cy, o.z - G.h.cz);
+  const float INF = __builtin_inff();
+  return (dot(oc, oc) <= G.h.far2) & (a > 0.0f) & (a < 1e30f) & (fabsf(d.x) < INF) & (fabsf(d.y) < INF) & (fabsf(d.z) < INF);
 }
 
 // variant 11's nearest-hit search: the grid when the build produced one, the brute-force loop otherwise
@@ -606,12 +726,8 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
   const float a = dot(d, d);
   const GridLds& G = *sc.grid;
   if (G.valid) {
-    // admitted rays only: finite, and starting within 5 E of the grid centre (the registration margins assume it)
-    const F3 oc = mk3(o.x - G.h.cx, o.y - G.h.cy, o.z - G.h.cz);
-    const float INF = __builtin_inff();
-    const bool admitted = (dot(oc, oc) <= G.h.far2) & (a > 0.0f) & (a < 1e30f) & (fabsf(d.x) < INF) & (fabsf(d.y) < INF) &
-                          (fabsf(d.z) < INF);
-    PT_STAT(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);  // waves that also run the brute-force loop
+    const bool admitted = grid_admits(G, o, d, a);
+    PT_STATW(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);  // waves that also run the brute-force loop
     if (admitted) return intersect_scene_grid(sc, G, n, o, d, a, t_hit, idx);
   }
   return intersect_scene_screened_large(sc, n, o, d, make_ray_const(d), t_hit, idx);

@@ -51,6 +51,14 @@
 #ifndef PT_GRID_MIN_WAVES
 #define PT_GRID_MIN_WAVES 6  // __launch_bounds__ 2nd argument of the grid kernel: <= 80 VGPRs
 #endif
+// Variant 12 (variant 11 with the walk and the shading decoupled per lane, pt_kernel.hip): a wave leaves the walk when this
+// many of its lanes have nothing left to do there
+#ifndef PT_GRID_PARK
+#define PT_GRID_PARK 48
+#endif
+#ifndef PT_GRID12_MIN_WAVES
+#define PT_GRID12_MIN_WAVES 4
+#endif
 #define PT_GRID_MAX_SPHERES 2048
 #define PT_GRID_MIN_SPHERES 192
 

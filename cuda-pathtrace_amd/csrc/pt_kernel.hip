@@ -17,9 +17,9 @@ namespace pt {
 // REF builds the kernel for the reference's own configuration -- 9 spheres (Scene.h:23), MAX_BOUNCES 5 (pathtrace.cu:7) -- as
 // compile-time constants: no generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
 template <int VAR>
-constexpr int kBlockThreads = (VAR == 11) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
+constexpr int kBlockThreads = (VAR == 11 || VAR == 12) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
 template <int VAR>
-constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : PT_MIN_WAVES;
+constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
 
 template <int RNG, int VAR, bool LEAN = false, bool REF = false>
 __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
   sc.small_only = !LEAN && (VAR == 6 || VAR == 8 || VAR == 10);
   constexpr bool kRegen = (VAR == 10 || VAR == 11);
   GridLds grid;
-  if constexpr (VAR == 11) {  // the frame's grid, built by build_grid_kernel just before this launch
+  if constexpr (VAR == 11 || VAR == 12) {  // the frame's grid, built by build_grid_kernel just before this launch
     grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene);
     sc.grid = &grid;
   }
@@ -143,7 +143,68 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       }
     }
   }
-  if constexpr (VAR >= 7 && !kRegen) {
+  if constexpr (VAR == 12) {
+    // Variant 11 with the nearest-hit search and the rest of the bounce at DIFFERENT times per lane.  In variant 11 a wave
+    // walks the grid until its slowest lane is done (a ray needs 7 test trips, the wave makes 21: a quarter of the lanes
+    // work) and only then shades.  Here a lane keeps its walk (GridWalk) across iterations of this loop: the wave leaves the
+    // walk as soon as PT_GRID_PARK of its lanes have nothing left to do, those lanes finish their search (exact step), shade,
+    // start their next ray -- next bounce, or next sample: the path regeneration of variant 10 -- and join the lanes that
+    // are still walking.  Shading then runs with >= PT_GRID_PARK of 64 lanes instead of 64, the walk with most lanes busy
+    // instead of a quarter.  Per pixel the sequence of operations is the reference's, as in variants 10 and 11.
+    int n = 0;
+    F3 o = eye, d = eye;
+    F3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);
+    GridWalk w;
+    w.a = 1.0f;
+    w.s = Near2{0.0f, 0.0f, 0};
+    w.tmax0 = w.tmax1 = w.tmax2 = w.tdel0 = w.tdel1 = w.tdel2 = 0.0f;
+    w.cidx = w.cs0 = w.cs1 = w.cs2 = 0;
+    w.left = w.k0 = w.k1 = w.n0 = w.n1 = 0u;
+    w.have_next = w.walking = false;
+    bool in_walk = false;  // a ray's search is under way
+    bool brute = false;    // ... on the brute-force path (the grid is absent or does not admit the ray)
+    for (;;) {
+      if (__builtin_amdgcn_ballot_w64(i < a.spp) == 0) break;
+      const bool ready = (i < a.spp) & !(in_walk & !brute & w.busy());
+      if (ready) {
+        if (in_walk) {  // the search of the ray in hand is over: exact step, shading (:156-196)
+          float t = 0.0f;
+          int idx = 0;
+          bool hit = false;
+          if (a.n_spheres > 0) {
+            if (brute) hit = intersect_scene_screened_large(sc, a.n_spheres, o, d, make_ray_const(d), t, idx);
+            else hit = grid_end(w, sc, grid, a.n_spheres, o, d, t, idx);
+          }
+          const bool escaped = !bounce_shade<RNG, 11>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
+          n++;
+          if (escaped | (n >= a.max_bounces)) {
+            if (!escaped) {
+              L.color = L.color + color;                 // :198
+              welford_update(var[0], luminance(color));  // :200
+            }
+            i++;
+            n = 0;
+          }
+          in_walk = false;
+        }
+        if (i < a.spp) {  // the next ray of this pixel
+          if (n == 0) {  // :219-229
+            rng.begin_sample((uint32_t)i);
+            primary_ray(rng, d);
+            o = eye;
+            color = mk3(0.0f, 0.0f, 0.0f);
+            mask = mk3(1.0f, 1.0f, 1.0f);
+          }
+          const float aa = dot(d, d);
+          brute = !(grid.valid && a.n_spheres > 0 && grid_admits(grid, o, d, aa));
+          if (!brute) grid_begin(w, grid, o, d, aa);
+          in_walk = true;
+        }
+      }
+      grid_trips<true>(w, grid, o, d, in_walk & !brute, i < a.spp, PT_GRID_PARK);
+    }
+  }
+  if constexpr (VAR >= 7 && !kRegen && VAR != 12) {
     const int draws = (a.spp != 1 ? 2 : 0) + 2 * a.max_bounces;  // consumed by a path that never escapes
     for (; i + 2 <= a.spp; i += 2) {
       Rng<RNG> g[2] = {rng, rng};
@@ -169,7 +230,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       }
     }
   }
-  if constexpr (!kRegen) {
+  if constexpr (!kRegen && VAR != 12) {
     for (; i < a.spp; i++) {  // :219
       rng.begin_sample((uint32_t)i);
       F3 dir;
@@ -195,7 +256,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
   } else {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
-                         VAR != 11;  // variant 11's LDS holds the grid until the last wave is done: plain stores there
+                         VAR != 11 && VAR != 12;  // variants 11, 12: the LDS holds the grid until the last wave is done: plain stores there
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
 #pragma unroll
@@ -469,7 +530,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 // LDS layout of a launch (pt_scene_lds.h): many-sphere scenes keep only the geometry in LDS
 // (variants 6, 8 and 10 -- the ones the automatic policy uses -- are also built for that layout)
 static inline bool lds_lean(int n, int variant) {
-  return variant == 11 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
+  return variant == 11 || variant == 12 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
 }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
@@ -479,7 +540,7 @@ static inline size_t scene_lds_f4(int n, int variant) {
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
-  if (variant == 11) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n) : 64;  // geometry + grid tables instead of the epilogue slice
+  if (variant == 11 || variant == 12) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n) : 64;  // geometry + grid tables instead of the epilogue slice
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
   return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
@@ -504,6 +565,9 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool 
       case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
       case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
       case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
+#if PT_BUILD_EXPERIMENTS
+      case 12: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 12, true> : pt::pixel_kernel<PT_RNG_XORWOW, 12, true>;
+#endif
       default: return nullptr;
     }
   }
@@ -534,12 +598,12 @@ extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
 }
 #endif
 
-int pt_kernel_num_variants(void) { return 12; }
+int pt_kernel_num_variants(void) { return 13; }
 
-int pt_kernel_block_threads(int variant) { return variant == 11 ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
+int pt_kernel_block_threads(int variant) { return (variant == 11 || variant == 12) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
 
 bool pt_kernel_has_variant(int variant) {
-  if (variant < 0 || variant >= 12) return false;
+  if (variant < 0 || variant >= 13) return false;
 #if PT_BUILD_EXPERIMENTS
   return true;
 #else
@@ -551,6 +615,7 @@ size_t pt_kernel_accel_bytes(void) { return pt::kGridAccelBytes; }
 
 
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar) {
+  if (variant == 12 && max_bounces < 1) variant = 11;
   return (const void*)select_kernel(rng_mode, variant, lds_lean(n_spheres, variant), ref_config(n_spheres, max_bounces, variant, planar));
 }
 
@@ -559,7 +624,7 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(
 int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 8 || variant == 10 || variant == 11) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
+  if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
   const size_t fixed = tail + ((pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2)) * sizeof(float4);
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - fixed - 2 * sizeof(float4)) / (5 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
@@ -572,6 +637,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
+  if (variant == 12 && a.max_bounces < 1) variant = 11;  // variant 12's loop assumes every ray is searched for
   pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant), ref_config(a.n_spheres, a.max_bounces, variant, a.planar != 0u));
   if (!fn) return hipErrorInvalidValue;
   PixelKernelArgs b = a;
@@ -582,7 +648,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
     if (e != hipSuccess) return e;
   }
-  if (variant == 11) {  // this frame's grid (the scene may have changed since the last one)
+  if (variant == 11 || variant == 12) {  // this frame's grid (the scene may have changed since the last one)
     if (!a.accel) return hipErrorInvalidValue;
     hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, stream);
     if (e != hipSuccess) return e;

@@ -11,16 +11,11 @@ namespace pt {
 // One iteration of the bounce loop (src/pathtrace.cu:155-196) at depth n; false = the ray left the scene
 // (:157-161, the path's colour has been added to L.color and the path is over).
 // PRIMARY (only ever with n == 0): o is the eye the scene image was staged for, see SceneLds::eyeg
-template <int RNG, int VAR, bool PRIMARY = false>
-__device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
-                                            Rng<RNG>& rng, Welford (&var)[4], int n) {
-  float t = 0.0f;
-  int idx = 0;
-  bool hit;
-  if constexpr (VAR == 11)
-    hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
-  else
-    hit = intersect_scene<VAR, PRIMARY>(sc, nsph, o, d, t, idx);
+// (bounce_once = the nearest-hit search + bounce_shade; variant 12 runs the two at different times)
+// the part of the iteration after intersectScene (:156): hit/t/idx are its results
+template <int RNG, int VAR>
+__device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc, F3& o, F3& d, F3& color, F3& mask,
+                                             Rng<RNG>& rng, Welford (&var)[4], int n, bool hit, float t, int idx) {
   if (!hit) {  // :157-161
     L.color = L.color + color;
     return false;
@@ -71,6 +66,19 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
     welford_update(var[3], t);
   }
   return true;
+}
+
+template <int RNG, int VAR, bool PRIMARY = false>
+__device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
+                                            Rng<RNG>& rng, Welford (&var)[4], int n) {
+  float t = 0.0f;
+  int idx = 0;
+  bool hit;
+  if constexpr (VAR == 11)
+    hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
+  else
+    hit = intersect_scene<VAR, PRIMARY>(sc, nsph, o, d, t, idx);
+  return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
 }
 
 // trace_ray: src/pathtrace.cu:150-201

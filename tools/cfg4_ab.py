@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""BASELINE config 4 (1000 spheres, 1024^2) closed and open at a given spp for alternative builds.  Usage: cfg4_ab.py spp name..."""
+"""BASELINE config 4 (1000 spheres, 1024^2) closed and open at a given spp for alternative builds.
+Usage: cfg4_ab.py spp name[:variant]...   (name = main or a directory under cuda-pathtrace_amd/alt)"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "--child":
     sys.path.insert(0, root)
-    if sys.argv[3] != "main":
-        os.environ["PT_LIB_OVERRIDE"] = os.path.join(root, "cuda-pathtrace_amd", "alt", sys.argv[3], "libptcore.so")
+    name, _, var = sys.argv[3].partition(":")
+    var = int(var) if var else None
+    if name != "main":
+        os.environ["PT_LIB_OVERRIDE"] = os.path.join(root, "cuda-pathtrace_amd", "alt", name, "libptcore.so")
     import __graft_entry__ as ge
     pt = ge.load_package(); pt.set_device(0)
     spp = int(sys.argv[2])
@@ -13,13 +16,13 @@ if sys.argv[1] == "--child":
     out = []
     for walls in (True, False):
         scene = pt.scene_random(1000, seed=1, with_walls=walls)
-        r = pt.Renderer(1024, 1024, spp)
+        r = pt.Renderer(1024, 1024, spp, variant=var)
         d_scene, n = pt.upload_scene(scene)
         d_out = pt.DeviceBuffer(1024 * 1024 * 56)
         ms = min(r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(3))
         out.append(f"{'closed' if walls else 'open'} {ms:8.3f} ms")
         r.destroy()
-    print(f"{sys.argv[3]:8s} spp {spp}: " + " | ".join(out), flush=True)
+    print(f"{sys.argv[3]:10s} spp {spp}: " + " | ".join(out), flush=True)
 else:
     for name in sys.argv[2:]:
         subprocess.call([sys.executable, __file__, "--child", sys.argv[1], name])

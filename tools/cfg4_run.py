@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 (1000 random spheres + walls, 1024 x 1024) at a given spp, for profiling:
-  cfg4_run.py [spp=16] [open|closed] [reps=2]"""
+  cfg4_run.py [spp=16] [open|closed] [reps=2]     (PT_TOOL_VARIANT=<n> in the environment selects a kernel variant)"""
 import os
 import sys
 
@@ -14,7 +14,8 @@ walls = not (len(sys.argv) > 2 and sys.argv[2] == "open")
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 scene = pt.scene_random(1000, seed=1, with_walls=walls)
 basis = pt.camera_basis(width=1024, height=1024)
-r = pt.Renderer(1024, 1024, spp)
+variant = int(os.environ["PT_TOOL_VARIANT"]) if os.environ.get("PT_TOOL_VARIANT") else None
+r = pt.Renderer(1024, 1024, spp, variant=variant)
 d_scene, n = pt.upload_scene(scene)
 d_out = pt.DeviceBuffer(1024 * 1024 * 14 * 4)
 ms = [r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(reps)]
