@@ -150,10 +150,10 @@ if IS_LAB:
 
 
 def variants():
-    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 10, 11; lab: 0..11)."""
+    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 10, 11; lab: 0..12)."""
     out = []
     o = RendererOpts()
-    for v in range(12):
+    for v in range(13):
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.variant = v
         h = _vp()

@@ -200,7 +200,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     return pt_fail(PT_EINVAL, "pt_renderer_create: fast_math has one kernel; leave variant at -1");
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
     return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11; "
-                              "the experiments 1-5, 7, 9 live in libptcore_lab.so)", o.variant);
+                              "the experiments 1-5, 7, 9, 12 live in libptcore_lab.so)", o.variant);
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
 

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
   if constexpr (NS > 0) a.n_spheres = NS;
   if constexpr (NB > 0) a.max_bounces = NB;
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES, mk3(a.eye[0], a.eye[1], a.eye[2]));
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES, mk3(a.eye[0], a.eye[1], a.eye[2]), false);
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
   const bool active = tp < a.tile_pixels;

@@ -651,18 +651,22 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
       const int l = (int)G.items[three ? k0 + 2u : k0];
       const float4 gi = G.geom[i], gj = G.geom[j], gl = G.geom[l];
       k0 += three ? 3u : (two ? 2u : 1u);
-      uint32_t doubts = near2_test(s, gi, i, o, d, a4, Tlim_hi) ? 1u : 0u;
-      if (two) doubts |= near2_test(s, gj, j, o, d, a4, Tlim_hi) ? 2u : 0u;
-      if (three) doubts |= near2_test(s, gl, l, o, d, a4, Tlim_hi) ? 4u : 0u;
-      if (__builtin_expect(doubts != 0u, 0)) near2_resolve(s, doubts, gi, i, gj, j, gl, l, o, d, walk.a, Tlim_hi);
+      // (the three flags stay lane masks in scalar registers; the bit field is formed only inside the rare block)
+      const bool di = near2_test(s, gi, i, o, d, a4, Tlim_hi);
+      bool dj = false, dl = false;
+      if (two) dj = near2_test(s, gj, j, o, d, a4, Tlim_hi);
+      if (three) dl = near2_test(s, gl, l, o, d, a4, Tlim_hi);
+      if (__builtin_expect(di | dj | dl, 0))
+        near2_resolve(s, (di ? 1u : 0u) | (dj ? 2u : 0u) | (dl ? 4u : 0u), gi, i, gj, j, gl, l, o, d, walk.a, Tlim_hi);
 #else
       const int i = (int)G.items[k0];
       const int j = (int)G.items[two ? k0 + 1u : k0];
       const float4 gi = G.geom[i], gj = G.geom[j];
       k0 += two ? 2u : 1u;
-      uint32_t doubts = near2_test(s, gi, i, o, d, a4, Tlim_hi) ? 1u : 0u;
-      if (two) doubts |= near2_test(s, gj, j, o, d, a4, Tlim_hi) ? 2u : 0u;
-      if (__builtin_expect(doubts != 0u, 0)) near2_resolve(s, doubts, gi, i, gj, j, gj, j, o, d, walk.a, Tlim_hi);
+      const bool di = near2_test(s, gi, i, o, d, a4, Tlim_hi);
+      bool dj = false;
+      if (two) dj = near2_test(s, gj, j, o, d, a4, Tlim_hi);
+      if (__builtin_expect(di | dj, 0)) near2_resolve(s, (di ? 1u : 0u) | (dj ? 2u : 0u), gi, i, gj, j, gj, j, o, d, walk.a, Tlim_hi);
 #endif
     }
   }

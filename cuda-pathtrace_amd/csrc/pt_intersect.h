@@ -449,7 +449,8 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
 
 template <int VAR, bool PRIMARY = false>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
-  // every ray but the primary one has a unit direction: its constants come from the workgroup's table (any other a: general routine)
+  // every ray but the primary one has a unit direction: its constants come from the workgroup's table (any other a: general
+  // routine).  Not in the lean layouts: their kernels mix depths in a wave (path regeneration), so both routines would run.
   const RayConst rc = (VAR >= 6 && !PRIMARY && !sc.lean) ? make_ray_const_unit(d, sc.rden1) : make_ray_const(d);
   if constexpr (VAR >= 5) {
     // Screening pays when most spheres are hit by most rays (the Cornell box: a ray inside six

@@ -85,7 +85,7 @@ struct PixelKernelArgs {
 };
 
 #ifndef PT_BUILD_EXPERIMENTS
-#define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9 (libptcore_lab.so)
+#define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9, 12 (libptcore_lab.so)
 #endif
 #define PT_VARIANT_FAST 100     // reported by pt_renderer_kernel_info for a fast_math renderer (pt_fast.hip)
 #define PT_FAST_LDS_SPHERES 64  // the fast kernel stages scenes up to this size into LDS, larger ones are read in place

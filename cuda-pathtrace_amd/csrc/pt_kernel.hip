@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
   constexpr bool kRegen = (VAR == 10 || VAR == 11);
   GridLds grid;
   if constexpr (VAR == 11 || VAR == 12) {  // the frame's grid, built by build_grid_kernel just before this launch
-    grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene);
+    grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene + a.scene_lds_f4);  // after the two small tables
     sc.grid = &grid;
   }
 
@@ -534,7 +534,7 @@ static inline bool lds_lean(int n, int variant) {
 }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
-  if (lds_lean(n, variant)) return 0;  // the lean builds read the caller's array directly
+  if (lds_lean(n, variant)) return pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2;  // the lean builds read the caller's array directly: only the two small tables
   return (size_t)n * 4 + (pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2) + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image, the unit-length table
 }
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the

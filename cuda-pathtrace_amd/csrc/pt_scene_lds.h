@@ -32,7 +32,7 @@ struct SceneLds {
   float4* eyeg;  // {eye - centre, |eye - centre|^2 - r*r}: the off and c of pathtrace.cu:73,76 for a ray that starts at the eye.
                  // Every PRIMARY ray of the frame does, so these nine subtractions and dot products per sphere are done once
                  // per workgroup instead of once per sample (same operands, same operations, same bits).
-  float* inv1;   // 1.0f / sqrtf(x) for the kUnitTabSize floats around 1.0f (normalize_unit_nb, pt_device.h); nullptr when nothing is staged
+  float* inv1;   // 1.0f / sqrtf(x) for the kUnitTabSize floats around 1.0f (normalize_unit_nb, pt_device.h); every exact kernel has it
   double* rden1; // make_ray_const(d).rden for dot(d, d) = the same kUnitTabSize floats (make_ray_const_unit)
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
@@ -64,18 +64,28 @@ struct SceneLds {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// lean: nothing of the scene is staged (many-sphere layouts read the caller's array); the two small tables are, at the
+// start of the block, unless the caller has no use for them (lean_tables = false: the fast kernel)
 template <bool WITH_PAIR>
-__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean, F3 eye) {
-  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, lean ? nullptr : reinterpret_cast<float*>(lds + 4 * n),
-             lean ? nullptr : reinterpret_cast<double*>(lds + 4 * n + kUnitTabSize / 4), lds + 4 * n + kUnitTabSize / 4 + kUnitTabSize / 2,
+__device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean, F3 eye,
+                                                bool lean_tables = true) {
+  float4* tab = lean ? lds : lds + 4 * n;
+  const bool tables = !lean | lean_tables;
+  SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, tables ? reinterpret_cast<float*>(tab) : nullptr,
+             tables ? reinterpret_cast<double*>(tab + kUnitTabSize / 4) : nullptr, lds + 4 * n + kUnitTabSize / 4 + kUnitTabSize / 2,
              spheres, lean, false, nullptr, 0xFFFFFFFFu};
   const float qnan = __builtin_nanf("");
-  if (lean) return s;  // nothing is staged
-  for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x)  // the literal expression of helper_math's normalize (contract C2)
-    s.inv1[i] = 1.0f / sqrtf(__uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i));
-  for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x) {  // make_ray_const's own refinement, evaluated on a = dot(d, d) itself
-    const float a = __uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i);
-    s.rden1[i] = ray_const_rden(2.0 * (double)a);
+  if (tables) {
+    for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x)  // the literal expression of helper_math's normalize (contract C2)
+      s.inv1[i] = 1.0f / sqrtf(__uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i));
+    for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x) {  // make_ray_const's own refinement, evaluated on a = dot(d, d) itself
+      const float a = __uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i);
+      s.rden1[i] = ray_const_rden(2.0 * (double)a);
+    }
+  }
+  if (lean) {  // nothing else is staged
+    __syncthreads();
+    return s;
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const pt_sphere sp = spheres[i];

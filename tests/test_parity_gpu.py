@@ -56,9 +56,9 @@ def test_matches_committed_fixture(pt, gpu, name):
 # ---- every kernel variant computes the same bits ---------------------------------------------------
 def _all_variants(pt, lab):
     """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 10, 11) from libptcore.so,
-    the experimental ones (1-5, 7, 9) from libptcore_lab.so."""
+    the experimental ones (1-5, 7, 9, 12) from libptcore_lab.so."""
     prod = pt.variants()
-    assert prod == [0, 6, 8, 10, 11] and lab.variants() == list(range(12))
+    assert prod == [0, 6, 8, 10, 11] and lab.variants() == list(range(13))
     return [(pt, v) for v in prod] + [(lab, v) for v in lab.variants() if v not in prod]
 
 
@@ -231,6 +231,9 @@ def test_uniform_grid_variant(pt, lab, oracle, gpu, rng):
             for v in (11, None):
                 img, _ = pt.render_frame(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=v)
                 assert_bit_exact(img, ref, f"grid {name} eye={eye} variant={v}")
+            # the lab library's variant 12 (same walk, decoupled from the shading per lane; a measured negative result)
+            img, _ = lab.render_frame(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=12)
+            assert_bit_exact(img, ref, f"grid {name} eye={eye} variant=12 (lab)")
     assert lab.grid_header(scenes["walls"])["valid"] == 1 and lab.grid_header(wide)["valid"] == 0
     r = pt.Renderer(size, size, 3, rng_mode=rng)
     assert r.kernel_info(400)["variant"] == 11
@@ -267,7 +270,7 @@ def test_many_sphere_lean_lds_layout(pt, oracle, gpu, rng):
     r = pt.Renderer(size, size, 3, rng_mode=rng)
     info = r.kernel_info(3000)
     r.destroy()
-    assert info["variant"] == 10 and info["lds_bytes"] == 4 * 64 * 14 * 4 and info["max_spheres"] == 1 << 26
+    assert info["variant"] == 10 and info["lds_bytes"] == 4 * 64 * 14 * 4 + 768 and info["max_spheres"] == 1 << 26
 
 
 # ---- full-size properties at BASELINE.json config 2 (1024 x 1024 x 1024 spp) ----------------------------

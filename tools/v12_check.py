@@ -5,7 +5,7 @@ import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import __graft_entry__ as ge
-pt = ge.load_package(); pt.set_device(0)
+pt = ge.load_lab(); pt.set_device(0)  # variant 12 is an experiment: lab library only
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 bad = 0
 for (w, h, nsph, walls, rng_mode, mb) in [(1024, 1024, 1000, True, 0, 5), (1024, 1024, 1000, False, 0, 5), (1024, 1024, 1000, True, 1, 5),
