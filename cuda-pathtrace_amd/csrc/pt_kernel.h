@@ -40,7 +40,8 @@
 // 9-sphere scene with many).
 #define PT_LDS_BUDGET_BYTES (96 * 1024)
 // Variant 11 (uniform grid, pt_grid.h) stages the geometry of every sphere (16 B each) beside its tables; it pays from
-// about 200 spheres (150 spheres + walls: 3.2 vs 3.0-3.3 ms, 300: 5.9 vs 4.3, 1000: 18.1 vs 7.6; tools/grid_check.py).
+// about 160 spheres (16 spp, variant 10 vs 11: 120 spheres + walls 4.56 vs 5.22 ms, 180: 6.15 vs 5.99, 1000: 32.1 vs 9.3;
+// without walls 120: 1.24 vs 1.04, 180: 1.92 vs 1.22; tools/many_ab.py).
 #ifndef PT_GRID_BLOCK_THREADS
 // The grid kernel (variant 11) is latency-bound -- dependent LDS reads and a long dependency chain per sphere test -- so it
 // wants WAVES, and its 36 KB LDS image (geometry + tables at 1000 spheres) is per workgroup: 256-thread workgroups stop at
@@ -60,7 +61,7 @@
 #define PT_GRID12_MIN_WAVES 4
 #endif
 #define PT_GRID_MAX_SPHERES 2048
-#define PT_GRID_MIN_SPHERES 192
+#define PT_GRID_MIN_SPHERES 160
 
 // Everything pixel_kernel needs travels as kernel arguments (SGPRs): the camera is 60 B, so
 // the reference's two per-frame cudaMemcpy H2D (Renderer.h:59-60) disappear.
