@@ -398,8 +398,8 @@ struct Near2 {
 };
 
 // One sphere for one lane: the float part and the estimate of intersect_scene_screened_large, predicated.
-// Returns "doubt": the estimate cannot be trusted (the exact discriminant is within the rounding error of the reference's
-// float `det`, whose sign decides hit or miss; or an operand is zero / not finite).  Such a sphere has NOT been entered:
+// Returns "doubt": the estimate cannot be trusted (its numerator has lost its leading digits: the ray starts within
+// rounding distance of the sphere's surface; pt_intersect.h, screen_sphere_oc).  Such a sphere has NOT been entered:
 // near2_exact() decides it with the reference's own expression.  (Until round 2 a doubt anywhere sent the lane to the
 // literal loop over ALL spheres of the scene: 5e-4 of the lanes per bounce at 1000 spheres -- one lane in 2.4 % of the
 // wave-bounces -- and with it a quarter of the frame time in the closed and 40 % in the open configuration.)
@@ -422,8 +422,7 @@ __device__ __forceinline__ bool near2_test(Near2& s, const float4 g, int i, F3 o
   // the root the reference returns: origin inside (c < 0) the larger, outside the smaller (screen_sphere, pt_intersect.h)
   const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));
   const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
-  const float m = fabsf(a4c) * 4.7683716e-07f;  // 2^-21 |4ac|
-  const bool sure = fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(a4c)) > m;
+  const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);  // num = a4c + e keeps its leading digits (screen_sphere_oc)
   const bool ok = cand & sure & ((int)__float_as_uint(T) >= 0) & (T < Tlim_hi);
   const float Te = ok ? T : INF;
   s.i1 = Te < s.T1 ? i : s.i1;

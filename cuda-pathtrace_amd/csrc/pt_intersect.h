@@ -208,8 +208,8 @@ __device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, c
   const float hh = h * h;                          // bb / 4
   const float ac = rc.a * c;                       // 4ac / 4
   // The contract's det = RN(bb - RN(4a*c)) is used only through its sign.  dacc below rounds the exact
-  // bb - 4a*c once; the two can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|, and such spheres are
-  // flagged unsure (|dacc| > 2^-21 |4ac| is required), so det itself need not be formed.
+  // bb - 4a*c once; the two can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|, and then the winner's exact
+  // step decides (see the note on `unsure` below), so det itself need not be formed here.
   const float dacc = fmaf(-rc.a, c, hh);           // one rounding of the contract's exact discriminant (bb - 4ac) / 4
   const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the sign bit of dacc rejects it below
   const float q = h + copysignf(s, h);             // |h| + s with h's sign: no cancellation
@@ -226,13 +226,25 @@ __device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, c
   const uint32_t w = __float_as_uint(dacc) | __float_as_uint(T);
   uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
   key = (key & ~imask) | (uint32_t)i;
-  const float m = fabsf(ac) * 4.7683716e-07f;  // 2^-21 |4ac| (/ 4) >> the rounding errors of num (and of det vs dacc)
-  st.unsure = st.unsure | !(fminf(fminf(fabsf(num), fabsf(dacc)), fabsf(ac)) > m);
+  // When can the estimate not be trusted?  Only when num = ac + e has lost its leading digits (the small root then has no
+  // relative accuracy, and its SIGN -- which root the reference returns -- is open) or ac is zero: since |e| <= 2^-24 hh,
+  // |ac| > 2^-23 hh leaves |num| > |ac| / 2.  One fma and one compare; the floor covers hh below the normal range, where
+  // the bound on e is absolute.  (NaN on either side compares false = unsure.  A non-finite ac cannot belong to a sphere the
+  // reference returns, and if its garbage key wins or ties the winner's exact step sends the lane to the literal loop.)
+  // Until round 2 this also required |dacc| > 2^-21 |ac| -- the band in which the reference's twice-rounded float det can
+  // disagree in sign with dacc.  That is decided where it matters: a sphere wrongly taken for a hit can only do harm by
+  // winning, and the winner's exact step evaluates the reference's own det; a negative dacc means a negative exact
+  // discriminant, for which the reference's FP64 sqrt returns NaN and the hit is discarded (pathtrace.cu:80-88,99).
+  // dacc itself is one rounding of the exact value, so the estimate is as accurate there as anywhere.
+  st.unsure = st.unsure | !(fabsf(ac) > fmaf(hh, 1.1920929e-07f, 1e-30f));
   st.k2 = umed3(st.k1, st.k2, key);
   st.k1 = st.k1 < key ? st.k1 : key;
 }
 
 // PRIMARY: the ray starts at the eye the scene image was staged for -- off and c come from SceneLds::eyeg
+#ifdef PT_SCREEN_STATS
+__device__ unsigned long long g_screen_stats[8];
+#endif
 template <bool NB, bool PRIMARY = false>
 __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                               float& t_hit, int& idx) {
@@ -301,11 +313,30 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
       real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
     }
     const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+#ifdef PT_SCREEN_STATS  // instrumentation build only (tools/screen_stats.py): how often, and why, a lane takes the literal loop
+    {
+      const bool tie = has & ((k2 & ~imask) <= __float_as_uint(T1 * margin));
+      const bool lim = has & (T1 >= Tlim * 0.99998f);
+      const uint64_t any = __builtin_amdgcn_ballot_w64(ambiguous | (has & (bad | !good)));
+      if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+        atomicAdd(&g_screen_stats[0], 1ull);
+        atomicAdd(&g_screen_stats[1], any != 0 ? 1ull : 0ull);
+      }
+      atomicAdd(&g_screen_stats[2], (ambiguous | (has & (bad | !good))) ? 1ull : 0ull);
+      atomicAdd(&g_screen_stats[3], st.unsure ? 1ull : 0ull);
+      atomicAdd(&g_screen_stats[4], tie ? 1ull : 0ull);
+      atomicAdd(&g_screen_stats[5], lim ? 1ull : 0ull);
+      atomicAdd(&g_screen_stats[6], (has & bad) ? 1ull : 0ull);
+      atomicAdd(&g_screen_stats[7], (has & !good) ? 1ull : 0ull);
+    }
+#endif
     ambiguous = ambiguous | (has & (bad | !good));
     hit = has & good;
     t_hit = t;
     idx = i1;
-#ifndef PT_TIMING_ONLY_NO_ISECT_REDO
+#ifdef PT_TIMING_ONLY_DETECT_NO_REDO  // never defined in a shipped build: the detection stays, the literal loop goes
+    if (__builtin_expect(ambiguous, 0)) hit = false;
+#elif !defined(PT_TIMING_ONLY_NO_ISECT_REDO)
     if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
 #endif
     return hit;
@@ -372,8 +403,7 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
     const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
     const float T = lo > 0.0f ? lo : hi;
     const bool ok = ((int)(__float_as_uint(h.dacc) | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
-    const float m = fabsf(h.a4c) * 4.7683716e-07f;  // 2^-21 |4ac|
-    unsure = unsure | (cand & !(fminf(fminf(fabsf(num), fabsf(h.dacc)), fabsf(h.a4c)) > m));
+    unsure = unsure | (cand & !(fabsf(h.a4c) > fmaf(h.bb, 1.1920929e-07f, 1e-30f)));  // see screen_sphere_oc
     const float Te = ok ? T : INF;
     const bool c1 = Te < T1, c2 = Te < T2;
     T2 = c1 ? T1 : (c2 ? Te : T2);

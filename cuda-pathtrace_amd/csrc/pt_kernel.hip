@@ -589,6 +589,15 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool 
   }
 }
 
+#ifdef PT_SCREEN_STATS
+extern "C" int pt_debug_screen_stats(unsigned long long out[8], int reset) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_screen_stats), sizeof(zero)) != hipSuccess) return -2;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pt::g_screen_stats), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
 #ifdef PT_GRID_STATS
 extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
