@@ -196,14 +196,39 @@ struct ScreenState {
 // which spares the doubling of b per sphere: scaling by powers of two is exact, so every quantity below is exactly a
 // quarter (half for the root estimates T = a*t) of the contract-scale value it stands for, and every decision
 // (signs, relative margins, ranking) is the same one.
-__device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st);
-__device__ __forceinline__ void screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
-                                              ScreenState& st) {
+// Both return the sphere's KEY (the estimate's float bits with the index in the low bits, sign bit set = no candidate) and
+// record doubts in st.unsure; screen_insert ranks a key.
+__device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st);
+__device__ __forceinline__ uint32_t screen_sphere(const float4 g, int i, F3 o, F3 d, const RayConst& rc, uint32_t imask,
+                                                  ScreenState& st) {
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-  screen_sphere_oc(off, dot(off, off) - g.w, i, d, rc, imask, st);
+  return screen_sphere_oc(off, dot(off, off) - g.w, i, d, rc, imask, st);
+}
+__device__ __forceinline__ void screen_insert(ScreenState& st, uint32_t key) {
+  st.k2 = umed3(st.k1, st.k2, key);
+  st.k1 = st.k1 < key ? st.k1 : key;
+}
+// The two smallest of the nine keys key_of(0..8) through a small network instead of nine (min, med3) insertions: three
+// groups of three (min3 + med3), two merges of sorted pairs (min; min3 of the larger leader and the two runners-up):
+// 12 operations instead of 18.  st.k1 / st.k2 must still be empty.
+template <class F>
+__device__ __forceinline__ void screen_nine(ScreenState& st, F key_of) {
+  auto umin = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+  auto umax = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+  uint32_t lead[3], next[3];
+#pragma unroll
+  for (int g3 = 0; g3 < 3; g3++) {
+    const uint32_t x = key_of(3 * g3), y = key_of(3 * g3 + 1), z = key_of(3 * g3 + 2);
+    lead[g3] = umin(umin(x, y), z);
+    next[g3] = umed3(x, y, z);
+  }
+  const uint32_t l = umin(lead[0], lead[1]);
+  const uint32_t r2 = umin(umin(umax(lead[0], lead[1]), next[0]), next[1]);
+  st.k1 = umin(l, lead[2]);
+  st.k2 = umin(umin(umax(l, lead[2]), r2), next[2]);
 }
 // off = o - centre and c = dot(off, off) - r*r supplied by the caller (primary rays read them from SceneLds::eyeg)
-__device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st) {
+__device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 d, const RayConst& rc, uint32_t imask, ScreenState& st) {
   const float h = dot(d, off);                     // b / 2
   const float hh = h * h;                          // bb / 4
   const float ac = rc.a * c;                       // 4ac / 4
@@ -237,8 +262,7 @@ __device__ __forceinline__ void screen_sphere_oc(F3 off, float c, int i, F3 d, c
   // discriminant, for which the reference's FP64 sqrt returns NaN and the hit is discarded (pathtrace.cu:80-88,99).
   // dacc itself is one rounding of the exact value, so the estimate is as accurate there as anywhere.
   st.unsure = st.unsure | !(fabsf(ac) > fmaf(hh, 1.1920929e-07f, 1e-30f));
-  st.k2 = umed3(st.k1, st.k2, key);
-  st.k1 = st.k1 < key ? st.k1 : key;
+  return key;
 }
 
 // PRIMARY: the ray starts at the eye the scene image was staged for -- off and c come from SceneLds::eyeg
@@ -255,14 +279,15 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   const uint32_t imask = (1u << ib) - 1u;
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
   ScreenState st{0xFFFFFFFFu, 0xFFFFFFFFu, false};
-  auto screen = [&](const float4 g, int i) {
+  auto key_of = [&](const float4 g, int i) -> uint32_t {
     if constexpr (PRIMARY) {
       const float4 e = sc.eyeg[i];
-      screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, i, d, rc, imask, st);
+      return screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, i, d, rc, imask, st);
     } else {
-      screen_sphere(g, i, o, d, rc, imask, st);
+      return screen_sphere(g, i, o, d, rc, imask, st);
     }
   };
+  auto screen = [&](const float4 g, int i) { screen_insert(st, key_of(g, i)); };
   // Manually unrolled by three (hipcc does not runtime-unroll this loop on request): the three
   // LDS reads are issued together and the three dependency chains interleave, which is what
   // keeps a lone wave busy when a small tile leaves only ~2 waves per SIMD.
@@ -283,8 +308,7 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   }
 #if PT_UNROLL_NINE
   if (i == 0 && n == 9) {  // the reference's scene size (Scene.h:23): constant LDS offsets and indices, no loop state
-#pragma unroll
-    for (int u = 0; u < 9; u++) screen(sc.geom[u], u);
+    screen_nine(st, [&](int u) { return key_of(sc.geom[u], u); });
     i = 9;
   }
 #endif
@@ -529,22 +553,21 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
         const int j = __builtin_ctz(m);
         m &= m - 1u;
         const float4 e = sc.eyeg[j];
-        screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, j, d[0], rc[0], imask, st[0]);
+        screen_insert(st[0], screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, j, d[0], rc[0], imask, st[0]));
       }
       i = n;
     }
   }
 #if PT_UNROLL_NINE
   if (i == 0 && P == 1 && n == 9) {  // the reference's scene size: fully unrolled, constant offsets
-#pragma unroll
-    for (int u = 0; u < 9; u++) {
+    screen_nine(st[0], [&](int u) -> uint32_t {
       if constexpr (PRIMARY) {
         const float4 e = sc.eyeg[u];
-        screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, u, d[0], rc[0], imask, st[0]);
+        return screen_sphere_oc(mk3(e.x, e.y, e.z), e.w, u, d[0], rc[0], imask, st[0]);
       } else {
-        screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
+        return screen_sphere(sc.geom[u], u, o[0], d[0], rc[0], imask, st[0]);
       }
-    }
+    });
     i = 9;
   }
 #endif
@@ -552,14 +575,14 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     const float4 g0 = sc.geom[i], g1 = sc.geom[i + 1];
 #pragma unroll
     for (int p = 0; p < P; p++) {
-      screen_sphere(g0, i, o[p], d[p], rc[p], imask, st[p]);
-      screen_sphere(g1, i + 1, o[p], d[p], rc[p], imask, st[p]);
+      screen_insert(st[p], screen_sphere(g0, i, o[p], d[p], rc[p], imask, st[p]));
+      screen_insert(st[p], screen_sphere(g1, i + 1, o[p], d[p], rc[p], imask, st[p]));
     }
   }
   for (; i < n; i++) {
     const float4 g = sc.geom[i];
 #pragma unroll
-    for (int p = 0; p < P; p++) screen_sphere(g, i, o[p], d[p], rc[p], imask, st[p]);
+    for (int p = 0; p < P; p++) screen_insert(st[p], screen_sphere(g, i, o[p], d[p], rc[p], imask, st[p]));
   }
   bool ambiguous[P];
 #pragma unroll
