@@ -130,6 +130,9 @@ LAB_ABI = {
     "pt_debug_unary_map": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "pt_debug_unary_compare": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_debug_div_compare": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
+                                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.POINTER(ctypes.c_uint32)]),
     "pt_debug_grid_header": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
@@ -256,6 +259,14 @@ def unary_compare(fn_a, fn_b, first_bits=0, count=1 << 32):
     n, ex = ctypes.c_uint64(0), ctypes.c_uint32(0)
     check(lib.pt_debug_unary_compare(fn_a, fn_b, first_bits, count, ctypes.byref(n), ctypes.byref(ex)))
     return n.value, ex.value
+
+def div_compare(n_first, n_count, first_bits=0, count=1 << 32):
+    """Lab library: the kernels' division by a sample count (table reciprocal + exact remainder + one correction) against the
+    division itself for counts n_first .. n_first + n_count - 1 and `count` dividend bit patterns from first_bits.
+    Returns (mismatches, example dividend bits, example count)."""
+    n, ex, exn = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+    check(lib.pt_debug_div_compare(n_first, n_count, first_bits, count, ctypes.byref(n), ctypes.byref(ex), ctypes.byref(exn)))
+    return n.value, ex.value, exn.value
 
 
 class DeviceBuffer:

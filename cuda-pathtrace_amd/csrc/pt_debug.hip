@@ -52,6 +52,33 @@ __global__ void __launch_bounds__(256) unary_compare_kernel(int fn_a, int fn_b, 
   }
 }
 
+// the kernels' division by a sample count against the division: result[0] = mismatches, [1] = dividend bits, [2] = count
+__global__ void __launch_bounds__(256) div_compare_kernel(uint32_t n_first, uint32_t n_count, uint32_t first, uint64_t count,
+                                                          unsigned long long* result) {
+  unsigned long long bad = 0, ex_bits = 0, ex_n = 0;
+  for (uint32_t k = 0; k < n_count; k++) {
+    const uint32_t n = n_first + k;
+    const float nf = (float)n;
+    const float y = (n <= (uint32_t)kRcpTab) ? 1.0f / nf : __builtin_nanf("");  // what SceneLds::rcpn holds for this count
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+      const uint32_t bits = first + (uint32_t)i;
+      const float delta = __uint_as_float(bits);
+      const float a = div_by_count(delta, nf, y), b = delta / nf;
+      const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+      if (!same) {
+        bad++;
+        ex_bits = bits;
+        ex_n = n;
+      }
+    }
+  }
+  if (bad) {
+    atomicAdd(&result[0], bad);
+    atomicExch(&result[1], ex_bits);
+    atomicExch(&result[2], ex_n);
+  }
+}
+
 }  // namespace pt
 
 #define PT_HIPD(call)                                                                             \
@@ -85,6 +112,25 @@ extern "C" int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, u
   if (e != hipSuccess) return pt_fail(PT_EHIP, "pt_debug_unary_compare: %s", hipGetErrorString(e));
   *n_mismatch = h[0];
   if (example_bits) *example_bits = (uint32_t)h[1];
+  return PT_OK;
+}
+
+extern "C" int pt_debug_div_compare(uint32_t n_first, uint32_t n_count, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
+                                    uint32_t* example_bits, uint32_t* example_n) {
+  if (!n_mismatch || count > (1ull << 32) || n_first < 1 || n_count < 1 || n_count > 4096)
+    return pt_fail(PT_EINVAL, "pt_debug_div_compare: bad arguments");
+  unsigned long long* d = nullptr;
+  PT_HIPD(hipMalloc((void**)&d, 24));
+  PT_HIPD(hipMemset(d, 0, 24));
+  hipLaunchKernelGGL(pt::div_compare_kernel, dim3(16384), dim3(256), 0, 0, n_first, n_count, first_bits, count, d);
+  hipError_t e = hipGetLastError();
+  unsigned long long h[3] = {0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return pt_fail(PT_EHIP, "pt_debug_div_compare: %s", hipGetErrorString(e));
+  *n_mismatch = h[0];
+  if (example_bits) *example_bits = (uint32_t)h[1];
+  if (example_n) *example_n = (uint32_t)h[2];
   return PT_OK;
 }
 

@@ -148,6 +148,53 @@ __device__ __forceinline__ void welford_update(Welford& w, float x) {
   float delta2 = x - w.mean;
   w.M2 += delta * delta2;
 }
+
+// delta / (float)n of the update above (:52) without the division, n = 1, 2, ...  With y = the correctly rounded 1/(float)n
+// (SceneLds::rcpn: a per-workgroup LDS table filled by the division itself), q0 = delta * y, the exact remainder
+// r = delta - n * q0 and one correction give the correctly rounded quotient (Markstein) whenever q0 is a normal number or
+// delta is +0: a correctly rounded division is ~13 instructions, this is a multiply, two fmas and two integer range tests.  Not argued but
+// CHECKED: tests/test_unary_exhaustive_gpu.py compares it with the division for every one of the 2^32 float deltas and every
+// n of the table.  Anything else (q0 subnormal, zero, inf, NaN -- the table's last entry is a NaN, which is what n beyond
+// the table reads) takes the division.
+constexpr int kRcpTab = 1024;
+__device__ __forceinline__ float div_by_count(float delta, float nf, float y) {
+  const float q0 = delta * y;
+  const float r = fmaf(-nf, q0, delta);
+  float q = fmaf(r, y, q0);
+  // valid when q0 is a normal number (the remainder is then exact) or the dividend is +0 -- which it is whenever a sample
+  // equals the running mean, every sample of a pixel that sees one flat-shaded surface.  Integer tests on the bit patterns:
+  // __builtin_amdgcn_class(q0, normal) was seen to answer true for denormal products here (tools/ubench/div_probe.hip).
+  // (q0 enters the zero test so that the NaN reciprocal of a count beyond the table sends a zero dividend to the division too)
+  const bool ok = (((__float_as_uint(q0) & 0x7F800000u) - 0x00800000u) < 0x7F000000u) | ((__float_as_uint(delta) | __float_as_uint(q0)) == 0u);
+  if (__builtin_expect(!ok, 0)) q = delta / nf;
+  return q;
+}
+__device__ __forceinline__ float rcp_count(const float* __restrict__ rcpn, int n) {
+  const uint32_t k = (uint32_t)n - 1u;
+  return rcpn[k < (uint32_t)kRcpTab ? k : (uint32_t)kRcpTab];
+}
+__device__ __forceinline__ void welford_update(Welford& w, float x, const float* __restrict__ rcpn) {
+  w.n += 1;
+  const float delta = x - w.mean;
+  w.mean += div_by_count(delta, (float)w.n, rcp_count(rcpn, w.n));
+  const float delta2 = x - w.mean;
+  w.M2 += delta * delta2;
+}
+// the three first-hit accumulators (:187-195) are updated together or not at all: one count, one reciprocal
+__device__ __forceinline__ void welford_update3(Welford& a, Welford& b, Welford& c, float xa, float xb, float xc,
+                                                const float* __restrict__ rcpn) {
+  a.n += 1;
+  b.n = a.n;
+  c.n = a.n;
+  const float nf = (float)a.n, y = rcp_count(rcpn, a.n);
+  const float da = xa - a.mean, db = xb - b.mean, dc = xc - c.mean;
+  a.mean += div_by_count(da, nf, y);
+  b.mean += div_by_count(db, nf, y);
+  c.mean += div_by_count(dc, nf, y);
+  a.M2 += da * (xa - a.mean);
+  b.M2 += db * (xb - b.mean);
+  c.M2 += dc * (xc - c.mean);
+}
 __device__ __forceinline__ float welford_variance(const Welford& w) {
   return (w.n < 2) ? 0.0f : w.M2 / (float)(w.n - 1);
 }

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
   if constexpr (NS > 0) a.n_spheres = NS;
   if constexpr (NB > 0) a.max_bounces = NB;
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES, mk3(a.eye[0], a.eye[1], a.eye[2]), false);
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, NS == 0 && a.n_spheres > PT_FAST_LDS_SPHERES, mk3(a.eye[0], a.eye[1], a.eye[2]), 0, false);
 
   const uint32_t tp = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
   const bool active = tp < a.tile_pixels;
@@ -300,14 +300,14 @@ const void* pt_fast_kernel_symbol(int rng_mode, int n_spheres, int max_bounces) 
 }
 
 size_t pt_fast_kernel_lds_bytes(int n_spheres) {
-  const size_t scene = n_spheres > PT_FAST_LDS_SPHERES ? 0 : ((size_t)n_spheres * 4 + (pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2)) * sizeof(float4);
+  const size_t scene = n_spheres > PT_FAST_LDS_SPHERES ? 0 : ((size_t)n_spheres * 4 + pt::kTablesF4) * sizeof(float4);
   return scene + (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
 
 hipError_t pt_launch_fast_kernel(const PixelKernelArgs& a, int rng_mode, hipStream_t stream) {
   fast_kernel_fn fn = select_fast(rng_mode, a.n_spheres, a.max_bounces);
   PixelKernelArgs b = a;
-  b.scene_lds_f4 = a.n_spheres > PT_FAST_LDS_SPHERES ? 0u : (uint32_t)a.n_spheres * 4u + (uint32_t)((pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2));
+  b.scene_lds_f4 = a.n_spheres > PT_FAST_LDS_SPHERES ? 0u : (uint32_t)a.n_spheres * 4u + (uint32_t)(pt::kTablesF4);
   const size_t lds = pt_fast_kernel_lds_bytes(a.n_spheres);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);

@@ -38,7 +38,7 @@
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the
 // 9-sphere scene with many).
-#define PT_LDS_BUDGET_BYTES (96 * 1024)
+#define PT_LDS_BUDGET_BYTES (104 * 1024)
 // Variant 11 (uniform grid, pt_grid.h) stages the geometry of every sphere (16 B each) beside its tables; it pays from
 // about 160 spheres (16 spp, variant 10 vs 11: 120 spheres + walls 4.56 vs 5.22 ms, 180: 6.15 vs 5.99, 1000: 32.1 vs 9.3;
 // without walls 120: 1.24 vs 1.04, 180: 1.92 vs 1.22; tools/many_ab.py).

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     a.max_bounces = 5;
   }
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]));
+  SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
   // variants with a lean build run their LDS build only on scenes up to PT_SCREEN_MAX_SPHERES (launcher): the
   // many-sphere path is not even compiled into it, which keeps the hot loop's code small
   sc.small_only = !LEAN && (VAR == 6 || VAR == 8 || VAR == 10);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       if (escaped | (n >= a.max_bounces)) {
         if (!escaped) {
           L.color = L.color + color;                 // :198
-          welford_update(var[0], luminance(color));  // :200
+          if (sc.lean) welford_update(var[0], luminance(color)); else welford_update(var[0], luminance(color), sc.rcpn);  // :200
         }
         i++;
         n = 0;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
           if (escaped | (n >= a.max_bounces)) {
             if (!escaped) {
               L.color = L.color + color;                 // :198
-              welford_update(var[0], luminance(color));  // :200
+              if (sc.lean) welford_update(var[0], luminance(color)); else welford_update(var[0], luminance(color), sc.rcpn);  // :200
             }
             i++;
             n = 0;
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   }
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
-  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]));
+  SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
   sc.small_only = !LEAN && kSplit == 4;  // variant 8 has a lean build for larger scenes, variant 9 has not
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
         sum1[q] = en_sum ? sum1[q] + v.y : sum1[q];
         sum2[q] = en_sum ? sum2[q] + v.z : sum2[q];
         Welford wn = w[q];
-        welford_update(wn, v.w);
+        if (sc.lean) welford_update(wn, v.w); else welford_update(wn, v.w, sc.rcpn);
         w[q].n = en_w ? wn.n : w[q].n;  // field-wise: a struct select would go through scratch
         w[q].mean = en_w ? wn.mean : w[q].mean;
         w[q].M2 = en_w ? wn.M2 : w[q].M2;
@@ -534,8 +534,8 @@ static inline bool lds_lean(int n, int variant) {
 }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
-  if (lds_lean(n, variant)) return pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2;  // the lean builds read the caller's array directly: only the two small tables
-  return (size_t)n * 4 + (pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2) + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image, the unit-length table
+  if (lds_lean(n, variant)) return pt::kTablesF4;  // the lean builds read the caller's array directly: only the small tables
+  return (size_t)n * 4 + pt::kTablesF4 + (variant == 3 ? (size_t)((n + 1) / 2) * 2 : 0);  // geometry, two material slots, the eye image, the unit-length table
 }
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
@@ -634,7 +634,7 @@ int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
   if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
-  const size_t fixed = tail + ((pt::kUnitTabSize / 4 + pt::kUnitTabSize / 2)) * sizeof(float4);
+  const size_t fixed = tail + pt::kTablesF4 * sizeof(float4);
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - fixed - 2 * sizeof(float4)) / (5 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
 }

@@ -34,6 +34,7 @@ struct SceneLds {
                  // per workgroup instead of once per sample (same operands, same operations, same bits).
   float* inv1;   // 1.0f / sqrtf(x) for the kUnitTabSize floats around 1.0f (normalize_unit_nb, pt_device.h); every exact kernel has it
   double* rden1; // make_ray_const(d).rden for dot(d, d) = the same kUnitTabSize floats (make_ray_const_unit)
+  float* rcpn;   // 1.0f / (float)k for k = 1 .. min(spp, kRcpTab) at [k - 1], NaN at [kRcpTab] (welford_update, pt_device.h)
   float4* pair;  // spheres 2p,2p+1 side by side for packed FP32: {cx0,cx1,cy0,cy1}, {cz0,cz1,rr0,rr1}  (variant 3)
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
@@ -66,13 +67,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // lean: nothing of the scene is staged (many-sphere layouts read the caller's array); the two small tables are, at the
 // start of the block, unless the caller has no use for them (lean_tables = false: the fast kernel)
+// float4 slots of the three small tables (inv1, rden1, rcpn) that every layout keeps
+constexpr int kTablesF4 = kUnitTabSize / 4 + kUnitTabSize / 2 + (kRcpTab + 4) / 4;
+
 template <bool WITH_PAIR>
 __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ spheres, int n, float4* lds, bool lean, F3 eye,
-                                                bool lean_tables = true) {
+                                                int spp, bool lean_tables = true) {
   float4* tab = lean ? lds : lds + 4 * n;
   const bool tables = !lean | lean_tables;
   SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, tables ? reinterpret_cast<float*>(tab) : nullptr,
-             tables ? reinterpret_cast<double*>(tab + kUnitTabSize / 4) : nullptr, lds + 4 * n + kUnitTabSize / 4 + kUnitTabSize / 2,
+             tables ? reinterpret_cast<double*>(tab + kUnitTabSize / 4) : nullptr,
+             tables ? reinterpret_cast<float*>(tab + kUnitTabSize / 4 + kUnitTabSize / 2) : nullptr, lds + 4 * n + kTablesF4,
              spheres, lean, false, nullptr, 0xFFFFFFFFu};
   const float qnan = __builtin_nanf("");
   if (tables) {
@@ -82,6 +87,9 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
       const float a = __uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i);
       s.rden1[i] = ray_const_rden(2.0 * (double)a);
     }
+    const int counts = lean ? 0 : (spp < kRcpTab ? spp : kRcpTab);  // a pixel's accumulators never count beyond spp; lean layouts divide
+    for (int i = threadIdx.x; i < counts; i += blockDim.x) s.rcpn[i] = 1.0f / (float)(i + 1);  // the division of :52 itself
+    if (threadIdx.x == 0) s.rcpn[kRcpTab] = qnan;
   }
   if (lean) {  // nothing else is staged
     __syncthreads();

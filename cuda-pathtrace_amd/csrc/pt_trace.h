@@ -60,9 +60,13 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
     L.normal = L.normal + normal;
     L.albedo = L.albedo + scol;
     L.depth += t;
-    welford_update(var[1], luminance(normal));
-    welford_update(var[2], lum_col);
-    welford_update(var[3], t);
+    if (VAR >= 6 && !sc.lean) {  // (the many-sphere kernels keep the division: their registers are scarcer than their cycles here)
+      welford_update3(var[1], var[2], var[3], luminance(normal), lum_col, t, sc.rcpn);
+    } else {
+      welford_update(var[1], luminance(normal));
+      welford_update(var[2], lum_col);
+      welford_update(var[3], t);
+    }
   }
   return true;
 }
@@ -99,7 +103,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
       if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
   }
   L.color = L.color + color;                    // :198
-  welford_update(var[0], luminance(color));     // :200
+  if (VAR >= 6 && !sc.lean) welford_update(var[0], luminance(color), sc.rcpn); else welford_update(var[0], luminance(color));  // :200
 }
 
 // ---- variant 7: two samples of a pixel in lockstep ---------------------------------------------

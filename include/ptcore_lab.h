@@ -32,6 +32,12 @@ int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
  * (count <= 2^32); NaN results compare equal.  *n_mismatch = number of differing inputs. */
 int pt_debug_unary_compare(int fn_a, int fn_b, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
                            uint32_t* example_bits);
+/* The Welford update's division by the sample count (pathtrace.cu:52) as the kernels evaluate it -- reciprocal from a table,
+ * exact remainder, one correction (pt_device.h, div_by_count) -- against the division itself, for the counts
+ * n_first .. n_first + n_count - 1 and the `count` consecutive float bit patterns of the dividend starting at first_bits.
+ * *n_mismatch = number of (count, dividend) pairs whose quotients differ in any bit (NaN == NaN). */
+int pt_debug_div_compare(uint32_t n_first, uint32_t n_count, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch,
+                         uint32_t* example_bits, uint32_t* example_n);
 /* Diagnostics: builds the uniform grid of kernel variant 11 for a scene and returns its 64-byte header
  * {valid, nx, ny, nz, origin xyz, cell size, 1/cell size, slack, centre xyz, (2E)^2, n_big, n_items}. */
 int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]);

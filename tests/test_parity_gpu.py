@@ -270,7 +270,7 @@ def test_many_sphere_lean_lds_layout(pt, oracle, gpu, rng):
     r = pt.Renderer(size, size, 3, rng_mode=rng)
     info = r.kernel_info(3000)
     r.destroy()
-    assert info["variant"] == 10 and info["lds_bytes"] == 4 * 64 * 14 * 4 + 768 and info["max_spheres"] == 1 << 26
+    assert info["variant"] == 10 and info["lds_bytes"] == 4 * 64 * 14 * 4 + 4880 and info["max_spheres"] == 1 << 26
 
 
 # ---- full-size properties at BASELINE.json config 2 (1024 x 1024 x 1024 spp) ----------------------------

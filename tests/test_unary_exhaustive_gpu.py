@@ -59,3 +59,16 @@ def test_device_sincos_and_uniform_equal_oracle(lab, oracle, gpu):
     # and the definition itself stays within 2 ulp of the true value
     err = np.abs(s_dev.astype(np.float64) - np.sin(phi.astype(np.float64))) / np.spacing(np.abs(np.sin(phi.astype(np.float64))).astype(np.float32))
     assert err.max() < 2.0
+
+
+def test_division_by_sample_count_equals_the_division_for_every_float(lab, gpu):
+    """The Welford update's delta / n (pathtrace.cu:52) is evaluated with the count's reciprocal from a table, the exact
+    remainder and one correction (pt_device.h, div_by_count).  Every one of the 2^32 dividends against the division, for every
+    count the table holds (1 .. 1024) -- 4.4e12 quotients -- and for counts beyond it, which must take the division."""
+    for n_first in range(1, 1025, 128):
+        bad, ex, exn = lab.div_compare(n_first, 128, 0, 1 << 32)
+        assert bad == 0, f"{bad} quotients differ, e.g. dividend bits 0x{ex:08x} / {exn}"
+    for n_first in (1025, 4095, 65535, 16777215):
+        bad, ex, exn = lab.div_compare(n_first, 2, 0, 1 << 32)
+        assert bad == 0, f"{bad} quotients differ beyond the table, e.g. dividend bits 0x{ex:08x} / {exn}"
+
