@@ -405,8 +405,10 @@ __device__ __forceinline__ bool intersect_sphere_v1(F3 o, F3 d, const RayConst& 
 // One deferred branch per step instead of ~15 tiny ones per bounce keeps the code straight-line
 // (bigger scheduling regions, fewer scalar branch instructions), which matters most when a
 // small tile leaves only two waves per SIMD.
+// CHECKED = false: the caller knows x to be inside the verified range (2^-100 .. 2^100), see bounce_geometry
+template <bool CHECKED = true>
 __device__ __forceinline__ float sqrt_cr_f32_nb(float x, bool& bad) {
-  bad = bad | !in_fast_range(x);
+  if constexpr (CHECKED) bad = bad | !in_fast_range(x);
   const float y = __builtin_amdgcn_rsqf(x);
   const float s0 = x * y;
   const float h = 0.5f * y;
@@ -414,19 +416,21 @@ __device__ __forceinline__ float sqrt_cr_f32_nb(float x, bool& bad) {
   return fmaf(r, h, s0);
 }
 
+template <bool CHECKED = true>
 __device__ __forceinline__ float inv_sqrt_spec_nb(float x, bool& bad) {
   const float y = __builtin_amdgcn_rsqf(x);
   const float s0 = x * y;
   const float h = 0.5f * y;
   const float r = fmaf(-s0, s0, x);
   const float s1 = fmaf(r, h, s0);
-  bad = bad | !in_fast_range(x);
+  if constexpr (CHECKED) bad = bad | !in_fast_range(x);
   const float e = fmaf(-s1, y, 1.0f);
   const float inv = fmaf(e, y, y);
   return __uint_as_float(__float_as_uint(inv) + (((__float_as_uint(s1) & 0x7FFFFFu) == 0x7FFFFFu) ? 1u : 0u));
 }
 
-__device__ __forceinline__ F3 normalize_nb(F3 v, bool& bad) { return v * inv_sqrt_spec_nb(dot(v, v), bad); }
+template <bool CHECKED = true>
+__device__ __forceinline__ F3 normalize_nb(F3 v, bool& bad) { return v * inv_sqrt_spec_nb<CHECKED>(dot(v, v), bad); }
 
 // normalize() of a vector that is ALREADY of unit length up to rounding (the second normalisation of the shading normal,
 // the cross product of two orthogonal unit vectors, the cosine-weighted combination: pathtrace.cu:127,129,180).  Its squared
@@ -517,9 +521,12 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
   float ry, oneminus;
   if constexpr (FAST) {
     if constexpr (TAB) dir = normalize_unit_nb(normal, unit_tab, bad); else dir = normalize_nb(normal, bad);
-    o1 = normalize_nb(ortho_vector(dir), bad);
+    // Two range tests the table form makes redundant: unless `bad` is already raised, dir has unit length to within the
+    // table's window, and ortho_vector drops the smaller of two of its components -- its squared length is within
+    // [0.49, 1.01]; u_el is a curand_uniform value, 2^-33 .. 1 (Rng::bounce; the callers' placeholder is 0.5).
+    o1 = normalize_nb<!TAB>(ortho_vector(dir), bad);
     if constexpr (TAB) o2 = normalize_unit_nb(cross(dir, o1), unit_tab, bad); else o2 = normalize_nb(cross(dir, o1), bad);
-    ry = sqrt_cr_f32_nb(u_el, bad);
+    ry = sqrt_cr_f32_nb<!TAB>(u_el, bad);
     oneminus = (float)sqrt_cr_nb(1.0 - (double)(ry * ry), bad);
   } else {
     dir = normalize(normal);
