@@ -358,11 +358,12 @@ def main():
                         "source": f"{vrec.get('source')} (rocprofv3 SQ_INSTS_VALU per launch / this run's kernel time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles "
                                   "per wave64 instruction, MI355X_MICROARCH.md)"}
                 cw = vrec.get("class_weighted")
-                if cw:  # what the kernel's own instruction mix can reach: half-rate and transcendental classes cost 4.1 / 8.1 / 16.2 cycles
+                if cw:  # what the kernel's own instruction mix can reach: half-rate and transcendental classes cost 4 / 8 / 16 cycles
                     valu["class_weighted"] = {"frac": cw["frac"], "costs_cycles": cw["costs_cycles"], "mix_per_sample": cw["mix_per_sample"],
                                               "clock_ghz": cw["clock_ghz"],
-                                              "note": "SIMD cycles the measured mix needs / SIMD cycles the kernel took, both from the profiled run "
-                                                      "(tools/issue_model.py, costs measured by tools/ubench/valu_clock)"}
+                                              "note": "SIMD cycles the measured mix needs at the architectural class costs / SIMD cycles the kernel "
+                                                      "took, both from the profiled run (tools/issue_model.py; the 1:2:4:8 ladder was "
+                                                      "measured by tools/ubench/valu_clock)"}
         out = {
             "metric": f"Msamples/s, 9-sphere Cornell box {WIDTH}x{HEIGHT}x{spp}spp",
             "value": round(total_samples / elapsed / 1e6, 2),
