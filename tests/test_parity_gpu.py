@@ -175,6 +175,16 @@ def test_edge_cases(pt, lab, oracle, gpu):
     b32 = pt.camera_basis(width=32, height=32)
     img, _ = pt.render_frame(32, 32, 4, spheres=one, basis=b32)
     assert_bit_exact(img, oracle.render(32, 32, 4, spheres=one, basis=b32), "one sphere")
+    # more samples than the table of sample-count reciprocals holds (1024): counts beyond it take the division, and an open
+    # scene makes the colour accumulator's count lag the sample index (escaped paths do not update it, pathtrace.cu:157-161)
+    b12 = pt.camera_basis(width=12, height=12)
+    for name, sph in (("closed", pt.scene_cornell()), ("open", pt.scene_cornell()[[0, 2, 4, 6, 7, 8]])):
+        for rng in (0, 1):
+            for v in (None, 6, 8):
+                img, _ = pt.render_frame(12, 12, 1300, spheres=sph, basis=b12, rng_mode=rng, variant=v)
+                if v is None:
+                    ref = oracle.render(12, 12, 1300, spheres=sph, basis=b12, rng_mode=rng)
+                assert_bit_exact(img, ref, f"1300 spp {name} rng={rng} variant={v}")
     # a zero-row tile is a no-op
     r = pt.Renderer(32, 32, 1, row_begin=5, row_end=5)
     d_scene, n = pt.upload_scene(pt.scene_cornell())
