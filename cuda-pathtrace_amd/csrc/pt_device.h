@@ -466,10 +466,14 @@ __device__ __forceinline__ float quotient_to_float_nb(double num, const RayConst
   double q = num * rc.rden;
   double rem = __builtin_fma(-q, rc.den, num);
   q = __builtin_fma(rem, rc.rden, q);
-  const uint32_t lo = (uint32_t)__double2loint(q), hi = (uint32_t)__double2hiint(q);
-  bad = bad | (((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u) | (((hi & 0x7FF00000u) - (903u << 20)) >= (247u << 20));
+  // Near a float rounding boundary the Markstein quotient's last ulp decides: redo.  The companion test of the literal
+  // form -- q outside the float normal range -- is left to the callers: every one of them accepts the result only if
+  // FLT_MIN <= t < 1e6 (`good`), and sends the lane to the literal loop otherwise.
+  const uint32_t lo = (uint32_t)__double2loint(q);
+  bad = bad | (((lo & 0x1FFFFFFFu) - 0x0FFFFFF8u) <= 0x10u);
   return (float)q;
 }
+constexpr float kMinGoodT = 1.17549435e-38f;  // FLT_MIN: a smaller positive t (a denormal float) is left to the literal code
 
 // intersect_sphere for a sphere already known to satisfy det >= 0 is NOT assumed: the float part
 // is recomputed and `real` returned exactly as the literal test would.

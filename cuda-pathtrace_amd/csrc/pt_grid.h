@@ -690,7 +690,7 @@ __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, 
   bool real = intersect_sphere_nb(o, d, rc, gw, t, bad);
   // the cheap sequences met an input outside their verified domain: the literal test, for the winner alone
   if (__builtin_expect(has & bad, 0)) real = intersect_sphere(o, d, rc.a, gw, t);
-  const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+  const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
   ambiguous = ambiguous | (has & !good);
   t_hit = t;
   idx = s.i1;

@@ -336,7 +336,7 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
     } else {
       real = intersect_sphere_nb(o, d, rc, sc.geom[has ? i1 : 0], t, bad);
     }
-    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
 #ifdef PT_SCREEN_STATS  // instrumentation build only (tools/screen_stats.py): how often, and why, a lane takes the literal loop
     {
       const bool tie = has & ((k2 & ~imask) <= __float_as_uint(T1 * margin));
@@ -492,7 +492,7 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
   float t;
   bool bad = false;
   const bool real = intersect_sphere_nb(o, d, rc, sc.geom_lane(i1), t, bad);
-  const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+  const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
   ambiguous = ambiguous | (has & (bad | !good));
   t_hit = t;
   idx = i1;
@@ -601,7 +601,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     } else {
       real = intersect_sphere_nb(o[p], d[p], rc[p], sc.geom[has ? i1 : 0], t, bad);
     }
-    const bool good = real & (t > 0.0f) & (t < 1000000.0f);
+    const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
     ambiguous[p] = ambiguous[p] | (has & (bad | !good));
     hit[p] = has & good;
     t_hit[p] = t;
