@@ -261,7 +261,9 @@ __device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 
   // winning, and the winner's exact step evaluates the reference's own det; a negative dacc means a negative exact
   // discriminant, for which the reference's FP64 sqrt returns NaN and the hit is discarded (pathtrace.cu:80-88,99).
   // dacc itself is one rounding of the exact value, so the estimate is as accurate there as anywhere.
+#ifndef PT_MUTANT_NO_DOUBT  // (a deliberately unsound build for tests/test_parity_gpu.py::test_ray_origins_on_sphere_surfaces to catch)
   st.unsure = st.unsure | !(fabsf(ac) > fmaf(hh, 1.1920929e-07f, 1e-30f));
+#endif
   return key;
 }
 

@@ -201,6 +201,49 @@ def test_edge_cases(pt, lab, oracle, gpu):
     assert e.value.code == -1 and "libptcore_lab" in str(e.value)
 
 
+def test_ray_origins_on_sphere_surfaces(pt, lab, oracle, gpu):
+    """The screen's doubt test (pt_intersect.h, screen_sphere_oc): an estimate is not trusted when the ray starts within
+    rounding distance of a sphere's surface -- c = |o - centre|^2 - r^2 is zero or a few ulps of |o - centre|^2 -- where the
+    small root's sign, i.e. WHICH root the reference returns, hangs on the rounding error of b*b.  Eyes placed exactly on,
+    one ulp inside and one ulp outside sphere surfaces (unit, radius-600 and radius-1e5 spheres), looking inwards, outwards
+    and along the tangent; every kernel family against the oracle."""
+    size = 24
+    scenes = []
+    base = pt.scene_cornell()
+    for radius, centre in ((1.0, (10.0, 20.0, 30.0)), (600.0, (50.0, 40.0, 80.0)), (1e5, (1e5 + 1.0, 40.8, 81.6))):
+        sph = base.copy()
+        sph["radius"][7] = radius
+        sph["pos"][7] = centre
+        scenes.append((radius, np.array(centre, dtype=np.float32), sph))
+    many = pt.scene_random(300, seed=9, with_walls=True)  # the same through the grid and the many-sphere loop
+    for radius, centre, sph in scenes:
+        for axis in range(3):
+            for nudge in (0, -1, 1, 4):
+                eye = centre.copy()
+                eye[axis] = np.float32(centre[axis] - np.float32(radius))
+                bits = eye[axis:axis + 1].view(np.int32)
+                bits += nudge if eye[axis] >= 0 else -nudge  # `nudge` ulps further from / closer to the centre
+                for yaw, pitch in ((-90.0, 0.0), (90.0, 0.0), (0.0, 0.0), (-45.0, 30.0)):
+                    e = tuple(float(x) for x in eye)
+                    basis = pt.camera_basis(e, yaw, pitch, size, size)
+                    ref = oracle.render(size, size, 2, spheres=sph, basis=basis, eye=e)
+                    for v in (None, 8, 10):
+                        img, _ = pt.render_frame(size, size, 2, spheres=sph, basis=basis, eye=e, variant=v)
+                        assert_bit_exact(img, ref, f"eye on r={radius} axis {axis} nudge {nudge} yaw {yaw} variant {v}")
+    radius, centre = float(many["radius"][10]), many["pos"][10].astype(np.float32)
+    for nudge in (0, 1):
+        eye = centre.copy()
+        eye[0] = np.float32(centre[0] - np.float32(radius))
+        eye[0:1].view(np.int32)[0] += nudge
+        e = tuple(float(x) for x in eye)
+        for yaw in (-90.0, 90.0, 0.0):
+            basis = pt.camera_basis(e, yaw, 0.0, size, size)
+            ref = oracle.render(size, size, 2, spheres=many, basis=basis, eye=e)
+            for v in (None, 10, 11):
+                img, _ = pt.render_frame(size, size, 2, spheres=many, basis=basis, eye=e, variant=v)
+                assert_bit_exact(img, ref, f"eye on a sphere of the 300-sphere scene, nudge {nudge} yaw {yaw} variant {v}")
+
+
 @pytest.mark.parametrize("rng", [0, 1])
 def test_planar_layout_is_the_transposed_frame(pt, lab, oracle, gpu, rng):
     """PT_LAYOUT_PLANAR writes [14][rows][width] (channel-first, coalesced without the LDS transpose); the values
