@@ -271,7 +271,10 @@ __device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 
 #ifdef PT_SCREEN_STATS
 __device__ unsigned long long g_screen_stats[8];
 #endif
-template <bool NB, bool PRIMARY = false>
+// LAST: the caller uses only the hit/miss decision and the index (the last bounce of a path of known length: emission of the
+// sphere hit, nothing else -- t, the hit point and the next ray are dead).  The winner's FP64 exact step is then replaced by
+// its float part and two certainty tests, see below.
+template <bool NB, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc, int n, F3 o, F3 d, const RayConst& rc,
                                                               float& t_hit, int& idx) {
   if (n <= 0) return false;
@@ -326,7 +329,30 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   const float T1 = __uint_as_float(k1 & ~imask);
   bool ambiguous = st.unsure | (has & (((k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
   bool hit = false;
-  if constexpr (NB) {
+  if constexpr (NB && LAST && !PRIMARY) {
+    // Only "which sphere, if any" is wanted.  The exact step exists to compute t and to confirm that the winner is a hit of
+    // the reference with 0 < t < 1e6; the ranking itself is the screen's.  Both confirmations can be had without FP64:
+    //  * the reference takes the sphere for a hit iff its float det = RN(bb - RN(4ac)) >= 0; det and the once-rounded dacc
+    //    agree in sign outside the band |dacc| <= 2^-24 |4ac| -- required here with the factor 2^-21 (the test the screen
+    //    dropped per sphere, for the winner alone), and a positive dacc makes the FP64 discriminant positive too;
+    //  * the estimate is within 1e-5 of the reference's t (that is what ranks the spheres), so T1 >= 1e-30 a (and
+    //    T1 < 0.99998 Tlim, tested above) puts t inside (0, 1e6) with room.
+    // A winner that fails either goes the usual way (exact step, literal loop).
+    const int i1 = (int)(k1 & imask);
+    const float4 g = sc.geom[has ? i1 : 0];
+    const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float h = dot(d, off);
+    const float c = dot(off, off) - g.w;
+    const float ac = rc.a * c;
+    const float dacc = fmaf(-rc.a, c, h * h);
+    const bool certain = (dacc > fabsf(ac) * 4.7683716e-07f) & (T1 >= rc.a * 1e-30f);
+    ambiguous = ambiguous | (has & !certain);
+    hit = has;
+    t_hit = T1;  // not a distance: the caller does not use it (LAST)
+    idx = i1;
+    if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+    return hit;
+  } else if constexpr (NB) {
     // straight-line: evaluate the winner unconditionally, decide afterwards
     const int i1 = (int)(k1 & imask);
     float t;
@@ -503,7 +529,7 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
   return hit;
 }
 
-template <int VAR, bool PRIMARY = false>
+template <int VAR, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
   // every ray but the primary one has a unit direction: its constants come from the workgroup's table (any other a: general
   // routine).  Not in the lean layouts: their kernels mix depths in a wave (path regeneration), so both routines would run.
@@ -513,7 +539,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
     // wall spheres hits all six).  In a many-sphere scene almost every test fails `det >= 0` for
     // the whole wave and the literal loop skips its FP64 part with one wave-uniform branch.
     if (!sc.lean && (sc.small_only || n <= PT_SCREEN_MAX_SPHERES))
-      return intersect_scene_screened_keys<(VAR >= 6), (PRIMARY && VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
+      return intersect_scene_screened_keys<(VAR >= 6), (PRIMARY && VAR >= 6), (LAST && VAR >= 6)>(sc, n, o, d, rc, t_hit, idx);
     if constexpr (VAR >= 6) return intersect_scene_screened_large(sc, n, o, d, rc, t_hit, idx);
     return intersect_scene_loop<1>(sc, n, o, d, rc, t_hit, idx);
   }

@@ -71,7 +71,9 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
   return true;
 }
 
-template <int RNG, int VAR, bool PRIMARY = false>
+// LAST (never with n == 0): the path ends after this iteration whatever happens, so nothing but colour is produced -- o, d and
+// the t handed to bounce_shade are dead, and the nearest-hit search may return any t (intersect_scene_screened_keys)
+template <int RNG, int VAR, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
                                             Rng<RNG>& rng, Welford (&var)[4], int n) {
   float t = 0.0f;
@@ -80,7 +82,7 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
   else
-    hit = intersect_scene<VAR, PRIMARY>(sc, nsph, o, d, t, idx);
+    hit = intersect_scene<VAR, PRIMARY, LAST>(sc, nsph, o, d, t, idx);
   return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
 }
 
@@ -94,8 +96,9 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
   if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
     if (!bounce_once<RNG, VAR, true>(L, sc, nsph, o, d, color, mask, rng, var, 0)) return;  // trace_ray starts at the eye
 #pragma unroll
-    for (int n = 1; n < 5; n++)
+    for (int n = 1; n < 4; n++)
       if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
+    if (!bounce_once<RNG, VAR, false, true>(L, sc, nsph, o, d, color, mask, rng, var, 4)) return;  // the last: colour only
   } else
 #endif
   {
