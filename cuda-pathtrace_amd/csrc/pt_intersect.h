@@ -552,7 +552,7 @@ __device__ __forceinline__ bool intersect_scene(const SceneLds& sc, int n, F3 o,
 }
 
 // nearest hit for P rays at once; same decisions as intersect_scene_screened_keys<true>
-template <int P, bool PRIMARY = false>
+template <int P, bool PRIMARY = false, bool LAST = false>  // LAST: see intersect_scene_screened_keys
 __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const F3 (&o)[P], const F3 (&d)[P],
                                                 bool (&hit)[P], float (&t_hit)[P], int (&idx)[P]) {
   RayConst rc[P];
@@ -620,6 +620,19 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
     const float T1 = __uint_as_float(st[p].k1 & ~imask);
     ambiguous[p] = st[p].unsure | (has & (((st[p].k2 & ~imask) <= __float_as_uint(T1 * margin)) | (T1 >= Tlim * 0.99998f)));
     const int i1 = (int)(st[p].k1 & imask);
+    if constexpr (LAST && !PRIMARY) {  // hit/miss and the index only: the winner's float part and two certainty tests
+      const float4 g = sc.geom[has ? i1 : 0];
+      const F3 off = mk3(o[p].x - g.x, o[p].y - g.y, o[p].z - g.z);
+      const float h = dot(d[p], off);
+      const float c = dot(off, off) - g.w;
+      const float dacc = fmaf(-rc[p].a, c, h * h);
+      const bool certain = (dacc > fabsf(rc[p].a * c) * 4.7683716e-07f) & (T1 >= rc[p].a * 1e-30f);
+      ambiguous[p] = ambiguous[p] | (has & !certain);
+      hit[p] = has;
+      t_hit[p] = T1;  // not a distance: unused by the caller
+      idx[p] = i1;
+      continue;
+    }
     float t;
     bool bad = false;
     bool real;

@@ -144,7 +144,8 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     res[p].albedo0 = mk3(0.0f, 0.0f, 0.0f);
     res[p].t0 = 0.0f;
   }
-  auto bounce = [&](int n) -> bool {  // false = every path of this lane has left the scene
+  // last: the final iteration of a path of known length -- only colour comes out of it (bounce_once's LAST)
+  auto bounce = [&](int n, bool last) -> bool {  // false = every path of this lane has left the scene
     bool any = false;
 #pragma unroll
     for (int p = 0; p < P; p++) any = any | alive[p];
@@ -154,6 +155,8 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     int idx[P];
     if (P == 1 && primary_at_zero && n == 0)
       intersect_paths<P, true>(sc, nsph, o, d, hit, t, idx);
+    else if (P == 1 && last && n > 0)
+      intersect_paths<P, false, true>(sc, nsph, o, d, hit, t, idx);
     else
       intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
     // stage 1 (straight-line for all paths, so their chains interleave): materials, draws, fast geometry
@@ -206,12 +209,12 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
   if (P == 1 && max_bounces == 5) {
 #pragma unroll
     for (int n = 0; n < 5; n++)
-      if (!bounce(n)) break;
+      if (!bounce(n, n == 4)) break;
   } else
 #endif
   {
     for (int n = 0; n < max_bounces; n++)
-      if (!bounce(n)) break;
+      if (!bounce(n, false)) break;
   }
 #pragma unroll
   for (int p = 0; p < P; p++) res[p].color = color[p];
