@@ -43,6 +43,7 @@ struct pt_renderer {
   // automatic variant choice (opts.variant == PT_VARIANT_AUTO)
   bool auto_variant;
   bool small_tile;         // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD one-lane-per-pixel waves per SIMD
+  bool philox_split;       // fewer than 12: where the four-lane kernel wins with the counter-based generator
   bool spec_ok;            // variant 8's speculation has not been failing on this scene
   uint32_t* d_fail;        // device counter written by variant 8
   uint32_t* h_fail;        // pinned host copy, valid once ev_fail has completed
@@ -88,9 +89,10 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 11;  // fewer tests: the uniform grid
   if (n_spheres > PT_SCREEN_MAX_SPHERES)
     return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
-  // philox is counter-based: no skip-ahead, no speculation, and the four-lane kernel needs fewer
-  // registers than variant 6 with the philox state (114 vs 131 VGPR) -- faster at every size measured
-  if (r->opts.rng_mode == PT_RNG_PHILOX) return r->spp >= 4 ? 8 : PT_DEFAULT_VARIANT;
+  // philox is counter-based: no skip-ahead, no speculation.  The four-lane kernel wins below twelve one-lane waves per
+  // SIMD (tools/philox_policy.py, 1024 spp: half frame 28.2 vs 28.7 ms, 1/8 frame 7.5 vs 8.7), the one-lane kernel above
+  // (full frame 53.9 vs 55.4 ms)
+  if (r->opts.rng_mode == PT_RNG_PHILOX) return (r->spp >= 4 && r->philox_split) ? 8 : PT_DEFAULT_VARIANT;
   // xorwow: splitting must amortise the generator skip-ahead and only pays on small tiles
   return (r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : PT_DEFAULT_VARIANT;
 }
@@ -221,6 +223,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->ev_start = r->ev_stop = nullptr;
   r->auto_variant = (o.variant == PT_VARIANT_AUTO);
   r->small_tile = false;
+  r->philox_split = true;
   r->spec_ok = true;
   r->d_fail = nullptr;
   r->h_fail = nullptr;
@@ -237,6 +240,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     if (e == hipSuccess) {
       const uint64_t simds = (uint64_t)prop.multiProcessorCount * 4u;
       r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD;
+      r->philox_split = (uint64_t)r->tile_pixels < simds * 64u * 12u;
     }
   }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_fail, sizeof(uint32_t));

@@ -508,9 +508,13 @@ def test_automatic_variant_policy(pt, oracle, gpu):
     big = pt.Renderer(1024, 1024, 8)
     assert big.kernel_info(9)["variant"] == 6
     big.destroy()
-    bigp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX)  # counter-based generator: four lanes per pixel always pay
-    assert bigp.kernel_info(9)["variant"] == 8
+    # counter-based generator: four lanes per pixel pay below twelve one-lane waves per SIMD (half a 1024^2 frame), not above
+    bigp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX)
+    assert bigp.kernel_info(9)["variant"] == 6
     bigp.destroy()
+    halfp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=512)
+    assert halfp.kernel_info(9)["variant"] == 8
+    halfp.destroy()
     few = pt.Renderer(256, 256, 2)  # too few samples to split
     assert few.kernel_info(9)["variant"] == 6
     few.destroy()
