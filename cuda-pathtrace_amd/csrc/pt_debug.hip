@@ -24,6 +24,17 @@ __device__ __forceinline__ float eval_unary(int fn, float x) {
     case PT_FN_UNIFORM: return uniform_from_u32(__float_as_uint(x));
     case PT_FN_ONEMINUS_LITERAL: return (float)sqrt(1.0 - (double)(x * x));
     case PT_FN_ONEMINUS_FAST: return (float)sqrt_cr(1.0 - (double)(x * x));
+    case PT_FN_ONEMINUS_F32: {
+      bool bad = false;
+      const float v = oneminus_f32_nb(x, bad);
+      return bad ? (float)sqrt(1.0 - (double)(x * x)) : v;
+    }
+    case PT_FN_ONEMINUS_F32_FLAG: {
+      bool bad = false;
+      (void)oneminus_f32_nb(x, bad);
+      return bad ? 1.0f : 0.0f;
+    }
+    case PT_FN_ZERO: return 0.0f;
     default: return __builtin_nanf("");
   }
 }

@@ -503,6 +503,28 @@ __device__ __forceinline__ bool intersect_sphere_nb_oc(F3 off, float c, F3 d, co
   return real;
 }
 
+// (float)sqrt(1.0 - (double)(ry * ry)) of getCosineWeightedNormal (:134) without FP64.  x = 1 - ry*ry is held exactly as
+// hi + lo (Fast2Sum), sqrt(hi) ~ s0 comes from v_rsq_f32, and one Newton step with the FULL residual (x - s0*s0, lo included)
+// lands within 2^-21 ulp of sqrt(x) before its final rounding.  That rounding is taken twice, with the step moved down and
+// up by 2^-43 s0 (>= 2^-20 ulp: more than the step's own error, and far more than the 2^-30 ulp by which the reference's
+// intermediate FP64 rounding can move a value across a tie): when both agree, the result is the reference's; when they do
+// not, or when hi is zero or too small to matter (ry*ry > 1 - 2^-24), `bad` is raised and the caller redoes the step literally.
+// Not argued but CHECKED for every float ry in [0, 1]: tests/test_unary_exhaustive_gpu.py.
+__device__ __forceinline__ float oneminus_f32_nb(float ry, bool& bad) {
+  const float w = ry * ry;
+  const float hi = 1.0f - w;
+  const float lo = (1.0f - hi) - w;  // exact: |1| >= |w|
+  const float y = __builtin_amdgcn_rsqf(hi);
+  const float s0 = hi * y;
+  const float h = 0.5f * y;
+  const float r = fmaf(-s0, s0, hi) + lo;
+  const float delta = r * h;
+  const float c = s0 * 1.1368684e-13f;  // 2^-43 s0
+  const float sa = s0 + (delta - c), sb = s0 + (delta + c);
+  bad = bad | (sa != sb) | !(hi > 5.9604645e-08f);
+  return sa;
+}
+
 // the geometric part of one bounce: src/pathtrace.cu:163-166,178-180
 struct BounceGeom {
   F3 normal;  // flipped shading normal
@@ -531,7 +553,7 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
     o1 = normalize_nb<!TAB>(ortho_vector(dir), bad);
     if constexpr (TAB) o2 = normalize_unit_nb(cross(dir, o1), unit_tab, bad); else o2 = normalize_nb(cross(dir, o1), bad);
     ry = sqrt_cr_f32_nb<!TAB>(u_el, bad);
-    oneminus = (float)sqrt_cr_nb(1.0 - (double)(ry * ry), bad);
+    if constexpr (TAB) oneminus = oneminus_f32_nb(ry, bad); else oneminus = (float)sqrt_cr_nb(1.0 - (double)(ry * ry), bad);
   } else {
     dir = normalize(normal);
     o1 = normalize(ortho_vector(dir));

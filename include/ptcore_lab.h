@@ -25,7 +25,10 @@ enum {
   PT_FN_UNIFORM = 6,          /* curand_uniform mapping of the argument's BIT PATTERN             */
   PT_FN_ONEMINUS_LITERAL = 7, /* (float)sqrt(1.0 - (double)(x*x)), pathtrace.cu:134               */
   PT_FN_ONEMINUS_FAST = 8,    /* same through the lean correctly rounded double sqrt              */
-  PT_FN_COUNT = 9
+  PT_FN_ONEMINUS_F32 = 9,     /* the same without FP64 (pt_device.h, oneminus_f32_nb), the literal where it flags itself */
+  PT_FN_ONEMINUS_F32_FLAG = 10, /* 1.0f where oneminus_f32_nb flags itself, else 0.0f                              */
+  PT_FN_ZERO = 11,
+  PT_FN_COUNT = 12
 };
 int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
 /* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits

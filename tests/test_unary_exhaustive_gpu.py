@@ -23,6 +23,18 @@ def test_oneminus_fast_equals_literal_on_all_elevations(lab, gpu):
     assert bad == 0, f"{bad} mismatches, e.g. 0x{example:08x}"
 
 
+def test_oneminus_without_fp64_equals_literal_on_all_elevations(lab, gpu):
+    """sqrt(1 - ry*ry) of getCosineWeightedNormal in FP32 (hi + lo of 1 - ry*ry, one Newton step with the full residual,
+    the final rounding taken twice with the step moved down and up: pt_device.h, oneminus_f32_nb): every float ry in [0, 1]
+    against (float)sqrt(1.0 - (double)(ry*ry)); where the routine flags itself the kernel redoes the step literally (the
+    harness does the same), and it may flag only a few inputs in a million."""
+    n = 0x3F800001
+    bad, example = lab.unary_compare(lab.FN_ONEMINUS_F32, lab.FN_ONEMINUS_LITERAL, 0, n)
+    assert bad == 0, f"{bad} elevations differ, e.g. bits 0x{example:08x}"
+    flagged, _ = lab.unary_compare(lab.FN_ONEMINUS_F32_FLAG, lab.FN_ZERO, 0, n)
+    assert 0 < flagged < n * 2e-6, flagged
+
+
 def test_device_literals_match_cpu(lab, oracle, gpu):
     rng = np.random.default_rng(5)
     bits = np.concatenate([rng.integers(0x00800000, 0x7F800000, 1 << 22, dtype=np.uint32),
