@@ -35,6 +35,7 @@ __device__ __forceinline__ float eval_unary(int fn, float x) {
       return bad ? 1.0f : 0.0f;
     }
     case PT_FN_ZERO: return 0.0f;
+    case PT_FN_UNIFORM_LITERAL: return uniform_from_u32_literal(__float_as_uint(x));
     default: return __builtin_nanf("");
   }
 }

@@ -89,9 +89,14 @@ __device__ __forceinline__ void xorwow_skip(Xorwow& s, int n) {
   s.v0 = v0; s.v1 = v1; s.v2 = v2; s.v3 = v3; s.v4 = v4;
 }
 
-// curand_uniform: (0,1]
-__device__ __forceinline__ float uniform_from_u32(uint32_t x) {
+// curand_uniform: (0,1] -- _curand_uniform's x * 2^-32 + 2^-33 (contract C5).  The product with a power of two is exact, so
+// the one fma below rounds the same exact sum the multiply-then-add form rounds: identical for every x (and checked for all
+// 2^32 of them, tests/test_unary_exhaustive_gpu.py), one instruction less per draw.
+__device__ __forceinline__ float uniform_from_u32_literal(uint32_t x) {
   return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+__device__ __forceinline__ float uniform_from_u32(uint32_t x) {
+  return fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f / 2.0f);
 }
 
 // Philox4x32-10, counter-based (contract C8): nothing is kept between samples.
@@ -561,7 +566,8 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
     ry = sqrtf(u_el);
     oneminus = (float)sqrt(1.0 - (double)(ry * ry));
   }
-  float rx = u_az * 2.0f * 3.141592654f;
+  // :131 u * 2.0f * 3.141592654f: doubling is exact, so the one product with 2 pi rounds the same real number
+  float rx = FAST ? u_az * (2.0f * 3.141592654f) : u_az * 2.0f * 3.141592654f;
   float sn, cs;
   pt_sincos(rx, sn, cs);
   F3 a = o1 * (cs * oneminus);

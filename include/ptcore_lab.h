@@ -28,7 +28,8 @@ enum {
   PT_FN_ONEMINUS_F32 = 9,     /* the same without FP64 (pt_device.h, oneminus_f32_nb), the literal where it flags itself */
   PT_FN_ONEMINUS_F32_FLAG = 10, /* 1.0f where oneminus_f32_nb flags itself, else 0.0f                              */
   PT_FN_ZERO = 11,
-  PT_FN_COUNT = 12
+  PT_FN_UNIFORM_LITERAL = 12, /* curand_uniform as multiply, then add (the kernels use the equivalent single fma) */
+  PT_FN_COUNT = 13
 };
 int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
 /* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits

@@ -35,6 +35,13 @@ def test_oneminus_without_fp64_equals_literal_on_all_elevations(lab, gpu):
     assert 0 < flagged < n * 2e-6, flagged
 
 
+def test_uniform_as_one_fma_equals_multiply_then_add_for_every_draw(lab, gpu):
+    """curand_uniform's x * 2^-32 + 2^-33: the kernels evaluate it as one fma (the product with a power of two is exact);
+    all 2^32 generator outputs against the multiply-then-add form."""
+    bad, example = lab.unary_compare(lab.FN_UNIFORM, lab.FN_UNIFORM_LITERAL, 0, 1 << 32)
+    assert bad == 0, f"{bad} draws differ, e.g. 0x{example:08x}"
+
+
 def test_device_literals_match_cpu(lab, oracle, gpu):
     rng = np.random.default_rng(5)
     bits = np.concatenate([rng.integers(0x00800000, 0x7F800000, 1 << 22, dtype=np.uint32),
