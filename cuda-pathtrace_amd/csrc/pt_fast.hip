@@ -17,6 +17,8 @@
 // the pixels).
 #include "pt_footprint.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(fast)
 
 namespace pt {
@@ -68,7 +70,8 @@ __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, cons
 // every valid key): one v_min_u32 per sphere instead of compares and selects; the winner's t is then evaluated again
 // at full precision.  Larger scenes use plain compares.
 // mask (wave-uniform): the spheres to rank -- all of them, or for a primary ray what the wave's pixel footprints leave (pt_footprint.h)
-template <int NS>
+// LAST: only hit/miss and the index are used by the caller (the last bounce of a path of known length): the key decides
+template <int NS, bool LAST = false>
 __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, uint32_t mask = 0xFFFFFFFFu) {
   const float a = dot3(d, d);
   const float inv_a = __builtin_amdgcn_rcpf(a);
@@ -99,6 +102,10 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
       for (int i = 0; i < n; i++) rank(sc.geom_uniform(i), i);
     }
     idx = (int)(best & imask);
+    if constexpr (LAST) {
+      t_hit = __uint_as_float(best & ~imask);  // the ranked t, low bits cleared (unused by the caller)
+      return ((best & ~imask) != 0u) & (best < 0x49742400u);  // 0 < t < 1e6 on the key (sign bit set = no candidate)
+    }
     float disc;
     const float t = sphere_t(o, d, a, inv_a, sc.geom_lane(idx), disc);
     t_hit = t;
@@ -193,10 +200,10 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
     F3 o = eye;
     F3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);
     bool escaped = false;
-    auto bounce = [&](int n) -> bool {  // :155-196; false = the ray left the scene
+    auto bounce = [&](int n, auto last) -> bool {  // :155-196; false = the ray left the scene
       float t;
       int idx;
-      if (!nearest<NS>(sc, a.n_spheres, o, d, t, idx, n == 0 ? prim_mask : 0xFFFFFFFFu)) return false;
+      if (!nearest<NS, decltype(last)::value>(sc, a.n_spheres, o, d, t, idx, n == 0 ? prim_mask : 0xFFFFFFFFu)) return false;
       const float4 g = sc.geom_lane(idx);
       F3 emis, scol;
       fetch_material(sc, idx, emis, scol);
@@ -232,12 +239,15 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
     };
     if constexpr (NB > 0) {
 #pragma unroll
-      for (int n = 0; n < NB; n++) {
-        if (!escaped && !bounce(n)) escaped = true;
+      for (int n = 0; n < NB - 1; n++) {
+        if (!escaped && !bounce(n, std::false_type{})) escaped = true;
       }
+      // the last bounce of a path of known length (more than one: the first hit's depth needs its t)
+      if (NB > 1) { if (!escaped && !bounce(NB - 1, std::true_type{})) escaped = true; }
+      else { if (!escaped && !bounce(NB - 1, std::false_type{})) escaped = true; }
     } else {
       for (int n = 0; n < a.max_bounces && !escaped; n++)
-        if (!bounce(n)) escaped = true;
+        if (!bounce(n, std::false_type{})) escaped = true;
     }
     Lc = Lc + color;  // :159 / :198
     if (!escaped) {   // :200
