@@ -6,7 +6,13 @@
 
 #include "../../include/ptcore.h"
 
+#ifndef PT_BLOCK_THREADS
 #define PT_BLOCK_THREADS 256
+#endif
+// one-lane-per-pixel kernels set their issue priority by progress from this many samples per pixel up (pt_kernel.hip)
+#ifndef PT_PRIO_MIN_SPP
+#define PT_PRIO_MIN_SPP 512
+#endif
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // requested unroll of the variant-2/4 screening loop (hipcc ignores it for runtime trip counts)
 #endif

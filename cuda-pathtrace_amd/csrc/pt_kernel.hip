@@ -231,12 +231,31 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     }
   }
   if constexpr (!kRegen && VAR != 12) {
+    // Issue priority by progress (long waves only).  A SIMD serves its waves oldest first: of four waves that start together
+    // the favoured one finishes in half the time its fair share would take and the last one finishes its work alone, which a
+    // lone wave cannot do at more than ~45 % of the SIMD's issue rate (a frame of 1024 workgroups x 4096 spp: first wave done
+    // after 27 ms, last after 61; tools/wave_timing.py) -- and the end of EVERY kernel looks like that.  With s_setprio
+    // 3, 2, 1, 0 by quarter of its own samples a wave that is ahead yields to the others on its SIMD, they reach the end
+    // together, and the tail disappears (the same frame: 54 ms; the headline's four rounds: 52.4 -> 50.8 ms).  Scheduling
+    // only: no value changes.  Not for short waves (the setting costs them 0.5 %; their kernels have many rounds anyway).
+    const bool by_progress = a.spp >= PT_PRIO_MIN_SPP;
+    const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
     for (; i < a.spp; i++) {  // :219
+      if (by_progress) {
+        const int iu = __builtin_amdgcn_readfirstlane(i);  // the sample index is the same in every lane that is in this loop
+        if ((iu & 15) == 0) {
+          if (iu < q1) __builtin_amdgcn_s_setprio(3);
+          else if (iu < q2) __builtin_amdgcn_s_setprio(2);
+          else if (iu < q3) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
       rng.begin_sample((uint32_t)i);
       F3 dir;
       primary_ray(rng, dir);
       trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
     }
+    if (by_progress) __builtin_amdgcn_s_setprio(0);
   }
 
   const float fs = (float)a.spp;  // :234-237
