@@ -182,7 +182,19 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
   }
 
   const int spp = active ? a.spp : 0;
+  // issue priority by progress, as in the exact kernels (pt_kernel.hip: why)
+  const bool by_progress = a.spp >= PT_PRIO_MIN_SPP;
+  const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
   for (int i = 0; i < spp; i++) {  // :219
+    if (by_progress) {
+      const int iu = __builtin_amdgcn_readfirstlane(i);
+      if ((iu & 15) == 0) {
+        if (iu < q1) __builtin_amdgcn_s_setprio(3);
+        else if (iu < q2) __builtin_amdgcn_s_setprio(2);
+        else if (iu < q3) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    }
     rng.begin_sample((uint32_t)i);
     float sx = (float)row, sy = (float)col;  // :221-226
     if (a.spp != 1) {
@@ -255,6 +267,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
       var_update(var[0], lum(color), nn, __builtin_amdgcn_rcpf(nn));
     }
   }
+  if (by_progress) __builtin_amdgcn_s_setprio(0);
 
   const float rs = __builtin_amdgcn_rcpf((float)a.spp);  // :234-237
   const float px[14] = {Lc.x * rs, Lc.y * rs, Lc.z * rs, Ln.x * rs, Ln.y * rs, Ln.z * rs, La.x * rs, La.y * rs, La.z * rs, Ld * rs,

@@ -13,6 +13,9 @@
 #ifndef PT_PRIO_MIN_SPP
 #define PT_PRIO_MIN_SPP 512
 #endif
+#ifndef PT_PRIO_MIN_SPP_REGEN  // the path-regeneration kernels (many-sphere scenes: a sample is long)
+#define PT_PRIO_MIN_SPP_REGEN 32
+#endif
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // requested unroll of the variant-2/4 screening loop (hipcc ignores it for runtime trip counts)
 #endif

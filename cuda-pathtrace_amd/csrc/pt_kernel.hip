@@ -120,7 +120,22 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     int n = 0;  // depth of the current path; 0 = start a new sample
     F3 o = eye, d = eye;
     F3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);
+    // issue priority by progress, as in the one-lane loop below (there: why); the progress of a wave is that of its first lane
+    const bool by_progress = a.spp >= PT_PRIO_MIN_SPP_REGEN;
+    const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
+    int last_band = -1;
     while (i < a.spp) {
+      if (by_progress) {
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+        const int band = (iu >= q1 ? 1 : 0) + (iu >= q2 ? 1 : 0) + (iu >= q3 ? 1 : 0);
+        if (band != last_band) {  // wave-uniform
+          last_band = band;
+          if (band == 0) __builtin_amdgcn_s_setprio(3);
+          else if (band == 1) __builtin_amdgcn_s_setprio(2);
+          else if (band == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
       if (n == 0) {  // :219-229
         rng.begin_sample((uint32_t)i);
         primary_ray(rng, d);
@@ -142,6 +157,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
         n = 0;
       }
     }
+    if (by_progress) __builtin_amdgcn_s_setprio(0);
   }
   if constexpr (VAR == 12) {
     // Variant 11 with the nearest-hit search and the rest of the bounce at DIFFERENT times per lane.  In variant 11 a wave
@@ -406,7 +422,22 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   bool seq = false;  // group-uniform: sequential mode after a failed speculation
   int base = 0;      // group-uniform: first sample of the current round
 
+  // issue priority by progress, as in pixel_kernel (there: why); the progress of a wave is that of its first pixel group
+  const bool by_progress = a.spp >= PT_PRIO_MIN_SPP;
+  const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
+  int last_band = -1;
   while (base < a.spp) {
+    if (by_progress) {
+      const int bu = __builtin_amdgcn_readfirstlane(base);
+      const int band = (bu >= q1 ? 1 : 0) + (bu >= q2 ? 1 : 0) + (bu >= q3 ? 1 : 0);
+      if (band != last_band) {  // wave-uniform
+        last_band = band;
+        if (band == 0) __builtin_amdgcn_s_setprio(3);
+        else if (band == 1) __builtin_amdgcn_s_setprio(2);
+        else if (band == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    }
     const int k = seq ? base : base + s;
     const bool mine = active && (!seq || s == 0) && k < a.spp;
     PathResult res[1];
@@ -497,6 +528,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
       if constexpr (RNG == PT_RNG_XORWOW) rng.st = final_state;
     }
   }
+  if (by_progress) __builtin_amdgcn_s_setprio(0);
 
   if (active) {  // :234-254, each lane stores its feature
     const float fs = (float)a.spp;
