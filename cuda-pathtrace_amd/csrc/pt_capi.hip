@@ -50,6 +50,8 @@ struct pt_renderer {
   hipEvent_t ev_fail;
   bool fail_pending;
   uint32_t* d_accel;       // variant 11's grid tables (rebuilt on the device before every frame)
+  uint32_t* d_chunk;       // sample chunking (pt_kernel.hip): PT_CHUNK_WORDS words per tile pixel + one flag per pixel block; or null
+  uint32_t chunks;         // how many chunks a frame of this renderer is split into when the kernel supports it (0 = off)
   // The renderer owns single-instance device scratch (generator state, d_accel, d_fail): launches of one
   // renderer must execute in submission order even when the caller alternates streams.
   hipEvent_t ev_last;      // recorded after every launch on the stream it went to
@@ -230,6 +232,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->ev_fail = nullptr;
   r->fail_pending = false;
   r->d_accel = nullptr;
+  r->d_chunk = nullptr;
+  r->chunks = 0;
   r->ev_last = nullptr;
   r->last_stream = nullptr;
   r->have_last = false;
@@ -248,6 +252,19 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_fail, sizeof(uint32_t), hipHostMallocDefault);
   if (e == hipSuccess) { *r->h_fail = 0; e = hipEventCreateWithFlags(&r->ev_fail, hipEventDisableTiming); }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_accel, pt_kernel_accel_bytes());
+  // Sample chunking pays on frames that make few rounds of long workgroups (tools/shape_sweep.py): at least 512 samples per
+  // pixel and at most 8 one-lane waves per SIMD slot-round.  The hand-over buffer is 112 B per tile pixel.
+  if (e == hipSuccess && r->spp >= 512 && r->tile_pixels > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
+      const uint64_t slots = (uint64_t)prop.multiProcessorCount * 4u * 4u * 64u;  // pixels resident at 4 waves per SIMD
+      if ((uint64_t)r->tile_pixels <= 8u * slots) {
+        const size_t blocks = ((size_t)r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
+        e = hipMalloc((void**)&r->d_chunk, ((size_t)PT_CHUNK_WORDS * r->tile_pixels + blocks) * sizeof(uint32_t));
+        if (e == hipSuccess) r->chunks = PT_CHUNKS;
+      }
+    }
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_last, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
@@ -271,6 +288,7 @@ int pt_renderer_destroy(pt_renderer* r) {
   if (!r) return PT_OK;
   if (r->d_state) (void)hipFree(r->d_state);  // Renderer.h:50
   if (r->d_accel) (void)hipFree(r->d_accel);
+  if (r->d_chunk) (void)hipFree(r->d_chunk);
   if (r->d_fail) (void)hipFree(r->d_fail);
   if (r->h_fail) (void)hipHostFree(r->h_fail);
   if (r->ev_fail) (void)hipEventDestroy(r->ev_fail);
@@ -310,6 +328,9 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->max_bounces = r->opts.max_bounces;
   a->frame = r->frame;
   a->seed = r->opts.seed;
+  a->chunks = r->chunks;  // the launcher keeps it only for the kernels that chunk (reference configuration, variant 6)
+  a->chunk_state = r->d_chunk;
+  a->chunk_flag = r->d_chunk ? r->d_chunk + (size_t)PT_CHUNK_WORDS * r->tile_pixels : nullptr;
   return PT_OK;
 }
 

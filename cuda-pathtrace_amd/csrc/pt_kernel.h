@@ -92,7 +92,16 @@ struct PixelKernelArgs {
   uint32_t* fail_count;        // variant 8: number of pixels whose speculation failed (may be nullptr)
   const uint32_t* accel;       // variant 11: the grid built by build_grid_kernel for this frame's scene
   uint64_t seed;
+  // sample chunking (reference-configuration variant 6 on frames that make few rounds of workgroups, pt_kernel.hip):
+  // a pixel block's samples are split over `chunks` workgroups of one launch, chained through chunk_state / chunk_flag
+  uint32_t chunks;             // 0 or 1 = off
+  uint32_t* chunk_state;       // PT_CHUNK_WORDS words per tile pixel, [word][pixel]
+  uint32_t* chunk_flag;        // per pixel block: number of chunks completed (zeroed before the launch)
 };
+#define PT_CHUNK_WORDS 28
+#ifndef PT_CHUNKS
+#define PT_CHUNKS 8
+#endif
 
 #ifndef PT_BUILD_EXPERIMENTS
 #define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9, 12 (libptcore_lab.so)

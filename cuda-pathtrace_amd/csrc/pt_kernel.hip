@@ -39,7 +39,21 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     sc.grid = &grid;
   }
 
-  const uint32_t tp = blockIdx.x * kBlockThreads<VAR> + threadIdx.x;  // pixel index inside the tile
+  // Sample chunking (REF builds of variant 6): workgroup blockIdx.x = chunk * n_blocks + block renders samples
+  // [chunk * per, (chunk + 1) * per) of its 256 pixels and hands generator, sums and Welford accumulators to the next chunk
+  // through chunk_state.  Workgroups are dispatched in index order, so the predecessor of a waiting workgroup is resident or
+  // done -- it never waits for anything itself -- and the wait cannot deadlock.  Same operations per pixel in the same order;
+  // what changes is that a frame of few, long workgroups becomes one of many short ones (tools/shape_sweep.py: why).
+  uint32_t block_id = blockIdx.x, chunk = 0u, n_chunks = 1u;
+  if constexpr (REF && VAR == 6) {
+    if (a.chunks > 1u) {
+      const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
+      n_chunks = a.chunks;
+      chunk = blockIdx.x / n_blocks;
+      block_id = blockIdx.x - chunk * n_blocks;
+    }
+  }
+  const uint32_t tp = block_id * kBlockThreads<VAR> + threadIdx.x;  // pixel index inside the tile
   const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
   const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
   const int col = (int)(tp % (uint32_t)a.width);
@@ -67,6 +81,35 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
 
   Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
   TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
+  int i_begin = 0, i_end = a.spp;
+  if constexpr (REF && VAR == 6) {
+    if (n_chunks > 1u) {
+      const int per = (a.spp + (int)n_chunks - 1) / (int)n_chunks;
+      i_begin = (int)chunk * per;
+      i_end = i_begin + per < a.spp ? i_begin + per : a.spp;
+      if (chunk > 0u) {
+        if (threadIdx.x == 0) {  // wait for the previous chunk of this pixel block
+          uint32_t spins = 0;
+          while (__hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 20)) break;  // ~1 s: never reached unless the launch is broken (the tests would see the image)
+          }
+        }
+        __syncthreads();
+        if (active) {
+          auto ld = [&](int w) { return __hip_atomic_load(a.chunk_state + (size_t)w * a.tile_pixels + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+          auto ldf = [&](int w) { return __uint_as_float(ld(w)); };
+          L.color = mk3(ldf(0), ldf(1), ldf(2));
+          L.normal = mk3(ldf(3), ldf(4), ldf(5));
+          L.albedo = mk3(ldf(6), ldf(7), ldf(8));
+          L.depth = ldf(9);
+#pragma unroll
+          for (int k = 0; k < 4; k++) var[k] = Welford{(int)ld(10 + 3 * k), ldf(11 + 3 * k), ldf(12 + 3 * k)};
+          if constexpr (RNG == PT_RNG_XORWOW) rng.st = Xorwow{ld(22), ld(23), ld(24), ld(25), ld(26), ld(27)};
+        }
+      }
+    }
+  }
 
   auto primary_ray = [&](Rng<RNG>& g, F3& dir) {  // :221-229
     float sx = (float)row, sy = (float)col;
@@ -109,7 +152,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
 #endif
   }
 
-  int i = active ? 0 : a.spp;  // inactive lanes trace nothing
+  int i = active ? i_begin : a.spp;  // inactive lanes trace nothing (i_begin: 0 unless this workgroup is a later chunk)
   if constexpr (kRegen) {
     // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
     // per lane): the sample loop and the bounce loop are flattened into one per-lane state machine, so a
@@ -254,9 +297,11 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     // 3, 2, 1, 0 by quarter of its own samples a wave that is ahead yields to the others on its SIMD, they reach the end
     // together, and the tail disappears (the same frame: 54 ms; the headline's four rounds: 52.4 -> 50.8 ms).  Scheduling
     // only: no value changes.  Not for short waves (the setting costs them 0.5 %; their kernels have many rounds anyway).
-    const bool by_progress = a.spp >= PT_PRIO_MIN_SPP;
-    const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
-    for (; i < a.spp; i++) {  // :219
+    const int span = i_end - i_begin;  // this workgroup's samples (all of them unless the frame is chunked)
+    const bool by_progress = span >= PT_PRIO_MIN_SPP;
+    const int q1 = i_begin + span / 4, q2 = i_begin + span / 2, q3 = i_end - span / 4;
+    const int i_stop = active ? i_end : i;
+    for (; i < i_stop; i++) {  // :219
       if (by_progress) {
         const int iu = __builtin_amdgcn_readfirstlane(i);  // the sample index is the same in every lane that is in this loop
         if ((iu & 15) == 0) {
@@ -272,6 +317,33 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
     }
     if (by_progress) __builtin_amdgcn_s_setprio(0);
+  }
+  if constexpr (REF && VAR == 6) {
+    if (chunk + 1u < n_chunks) {  // not the last chunk: hand the pixel's state over and leave
+      if (active) {
+        auto st = [&](int w, uint32_t v) { a.chunk_state[(size_t)w * a.tile_pixels + tp] = v; };
+        auto stf = [&](int w, float v) { st(w, __float_as_uint(v)); };
+        stf(0, L.color.x); stf(1, L.color.y); stf(2, L.color.z);
+        stf(3, L.normal.x); stf(4, L.normal.y); stf(5, L.normal.z);
+        stf(6, L.albedo.x); stf(7, L.albedo.y); stf(8, L.albedo.z);
+        stf(9, L.depth);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          st(10 + 3 * k, (uint32_t)var[k].n);
+          stf(11 + 3 * k, var[k].mean);
+          stf(12 + 3 * k, var[k].M2);
+        }
+        if constexpr (RNG == PT_RNG_XORWOW) {
+          st(22, rng.st.d); st(23, rng.st.v0); st(24, rng.st.v1); st(25, rng.st.v2); st(26, rng.st.v3); st(27, rng.st.v4);
+        }
+      }
+      __syncthreads();  // every wave's stores are issued ...
+      if (threadIdx.x == 0) {
+        __threadfence();  // ... and visible device-wide before the flag says so
+        __hip_atomic_store(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
   }
 
   const float fs = (float)a.spp;  // :234-237
@@ -715,7 +787,16 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   }
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);
   const unsigned block = (unsigned)pt_kernel_block_threads(variant);
-  const unsigned grid = (unsigned)((lanes + block - 1) / block);
+  unsigned grid = (unsigned)((lanes + block - 1) / block);
+  // sample chunking: only the reference-configuration build of variant 6 hands a pixel's state from workgroup to workgroup
+  const bool chunked = variant == 6 && !lds_lean(a.n_spheres, variant) && ref_config(a.n_spheres, a.max_bounces, variant, a.planar != 0u) &&
+                       a.chunks > 1u && a.chunk_state && a.chunk_flag && a.spp >= 2 * (int)a.chunks;
+  b.chunks = chunked ? a.chunks : 0u;
+  if (chunked) {
+    hipError_t e = hipMemsetAsync(a.chunk_flag, 0, (size_t)grid * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    grid *= a.chunks;
+  }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds, stream, b);
   return hipGetLastError();
 }

@@ -185,6 +185,22 @@ def test_edge_cases(pt, lab, oracle, gpu):
                 if v is None:
                     ref = oracle.render(12, 12, 1300, spheres=sph, basis=b12, rng_mode=rng)
                 assert_bit_exact(img, ref, f"1300 spp {name} rng={rng} variant={v}")
+    # sample chunking (frames of 512+ samples per pixel that make few rounds of workgroups: a pixel's samples go through
+    # several workgroups of one launch, its state through HBM): ragged last workgroup, a row tile, two frames with the
+    # generator state persisted, both generators, a sample count the chunks do not divide
+    b40 = pt.camera_basis(width=40, height=24)
+    for rng in (0, 1):
+        r = pt.Renderer(40, 24, 601, rng_mode=rng, row_begin=3, row_end=20, variant=6)  # (the automatic choice for so small a tile is 8)
+        d_scene, n = pt.upload_scene(pt.scene_cornell())
+        d_out = pt.DeviceBuffer(17 * 40 * 56)
+        st = oracle.setup_random(40, 24, row_begin=3, row_end=20) if rng == 0 else None
+        for frame in range(2):
+            r.render(d_out.ptr, d_scene.ptr, n, b40)
+            ref = oracle.render(40, 24, 601, spheres=pt.scene_cornell(), basis=b40, rng_mode=rng, rng_state=st, frame=frame,
+                                row_begin=3, row_end=20)
+            assert_bit_exact(d_out.download(np.float32, (17, 40, 14)), ref, f"chunked 601 spp rng={rng} frame {frame}")
+        assert r.kernel_info(n)["variant"] == 6
+        r.destroy()
     # a zero-row tile is a no-op
     r = pt.Renderer(32, 32, 1, row_begin=5, row_end=5)
     d_scene, n = pt.upload_scene(pt.scene_cornell())
