@@ -117,9 +117,6 @@ void pt_renderer_opts_default(pt_renderer_opts* opts);
  * Allocates the per-pixel generator state and runs setup_random (pathtrace.cu:259-266)
  * when rng_mode == PT_RNG_XORWOW && persist_rng.  threads_per_block is accepted for CLI
  * compatibility (main.cu:21,34) and ignored: the kernel picks its own workgroup shape.
- * Device memory owned by a renderer: 24 B per tile pixel of generator state (xorwow, persist_rng), 20.7 KB of grid tables,
- * and for tiles of at most 2 M pixels rendered with 512 or more samples per pixel 112 B per tile pixel of scratch (the
- * samples of a pixel are then chained through several workgroups of one launch).
  * opts may be NULL (= defaults). */
 int pt_renderer_create(int width, int height, int samples_per_pixel, int threads_per_block,
                        const pt_renderer_opts* opts, pt_renderer** out);
