@@ -445,6 +445,8 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->variant = variant;
   if (variant == 8 || variant == 9)
     info->grid_blocks = (int)(((uint64_t)r->tile_pixels * (variant == 8 ? 4 : 2) + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+  if (!fast && r->d_chunk && pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
+    info->grid_blocks *= (int)r->chunks;  // sample chunking: that many workgroups per pixel block
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;

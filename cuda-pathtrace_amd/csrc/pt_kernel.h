@@ -109,6 +109,7 @@ struct PixelKernelArgs {
 #define PT_VARIANT_FAST 100     // reported by pt_renderer_kernel_info for a fast_math renderer (pt_fast.hip)
 #define PT_FAST_LDS_SPHERES 64  // the fast kernel stages scenes up to this size into LDS, larger ones are read in place
 int pt_kernel_num_variants(void);
+bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks);
 int pt_kernel_block_threads(int variant);  // workgroup size the launcher uses
 bool pt_kernel_has_variant(int variant);  // compiled into this library?
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs

@@ -768,6 +768,12 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
   return hipGetLastError();
 }
 
+// does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?
+bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
+  return variant == 6 && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar) && chunks > 1u &&
+         spp >= 2 * (int)chunks;
+}
+
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
   if (variant == 12 && a.max_bounces < 1) variant = 11;  // variant 12's loop assumes every ray is searched for
   pixel_kernel_fn fn = select_kernel(rng_mode, variant, lds_lean(a.n_spheres, variant), ref_config(a.n_spheres, a.max_bounces, variant, a.planar != 0u));
@@ -789,8 +795,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   const unsigned block = (unsigned)pt_kernel_block_threads(variant);
   unsigned grid = (unsigned)((lanes + block - 1) / block);
   // sample chunking: only the reference-configuration build of variant 6 hands a pixel's state from workgroup to workgroup
-  const bool chunked = variant == 6 && !lds_lean(a.n_spheres, variant) && ref_config(a.n_spheres, a.max_bounces, variant, a.planar != 0u) &&
-                       a.chunks > 1u && a.chunk_state && a.chunk_flag && a.spp >= 2 * (int)a.chunks;
+  const bool chunked = pt_kernel_chunked(variant, a.n_spheres, a.max_bounces, a.planar != 0u, a.spp, a.chunks) && a.chunk_state && a.chunk_flag;
   b.chunks = chunked ? a.chunks : 0u;
   if (chunked) {
     hipError_t e = hipMemsetAsync(a.chunk_flag, 0, (size_t)grid * sizeof(uint32_t), stream);
