@@ -3,7 +3,11 @@
 
 Metric (BASELINE.json): Msamples/s (+ ms/frame) on the 9-sphere Cornell box, 1024 x 1024,
 1024 spp, fixed seed (--config cfg2, the default).  --config cfg3 is BASELINE.json configs[2]:
-4096 x 4096 x 64 spp, the 8-GPU row-tiled configuration.  A "step" is one frame: one pass of the
+4096 x 4096 x 64 spp, the 8-GPU row-tiled configuration; cfg4 / cfg4open are configs[3] (1000 spheres,
+1024 x 1024 x 256 spp, closed and open) and cfg5 is configs[4] (512 x 512 x 4 spp x 8 bounces, one frame per
+step, generator state carried from frame to frame) -- the reference prints its time for any --size/-s
+(src/main.cu:183), so every configuration has a bench line.  The default single-GPU run also measures those
+four after the headline (`other_configs`: kernel ms + Msamples/s).  A "step" is one frame: one pass of the
 hot path over the whole image.  At N GPUs the image is row-tiled (rank g renders rows
 row_range(H, N, g)) and gathered to rank 0 over RCCL at frame end; the timed region includes
 that gather.  Total work is fixed as N grows -> "scaling": "strong".
@@ -31,9 +35,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {  # BASELINE.json `configs`
-    "cfg2": {"width": 1024, "height": 1024, "spp": 1024, "name": "BASELINE.json configs[1]"},
-    "cfg3": {"width": 4096, "height": 4096, "spp": 64, "name": "BASELINE.json configs[2]"},
+    "cfg2": {"width": 1024, "height": 1024, "spp": 1024, "name": "BASELINE.json configs[1]", "scene": "cornell", "max_bounces": 5},
+    "cfg3": {"width": 4096, "height": 4096, "spp": 64, "name": "BASELINE.json configs[2]", "scene": "cornell", "max_bounces": 5},
+    # configs[3]: 1000 seeded random spheres inside the box, closed (6 wall spheres + light) and open (no walls: rays escape)
+    "cfg4": {"width": 1024, "height": 1024, "spp": 256, "name": "BASELINE.json configs[3], closed", "scene": "random1000_walls", "max_bounces": 5},
+    "cfg4open": {"width": 1024, "height": 1024, "spp": 256, "name": "BASELINE.json configs[3], open", "scene": "random1000_open", "max_bounces": 5},
+    # configs[4]: the interactive shape -- one step = one 512 x 512 x 4 spp frame, 8 bounces, generator state carried over
+    "cfg5": {"width": 512, "height": 512, "spp": 4, "name": "BASELINE.json configs[4], one frame per step", "scene": "cornell", "max_bounces": 8},
 }
+
+
+def scene_of(pt, cfg):
+    if cfg["scene"] == "cornell":
+        return pt.scene_cornell(), "9-sphere Cornell box"
+    walls = cfg["scene"].endswith("walls")
+    return pt.scene_random(1000, seed=1, with_walls=walls), ("1000 random spheres (seed 1) " + ("incl. 6 walls + light" if walls else "without walls"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL = 56   # 14 x f32 written per pixel per frame
 # VALU issue peak from MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
@@ -61,10 +77,11 @@ def cpu_baseline(oracle, cfg, spheres, basis, rows):
     is checked against; this is `value`) and -O3 -march=native (`native_build`, timing only)."""
     w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
     cores = usable_cores()
+    mb = cfg.get("max_bounces", 5)
     if rows <= 0:  # size the sample for about 8 s of wall time per build from a short probe, capped at the full frame
-        probe_rows = max(1, 8 * 1024 * 1024 // (w * spp))
+        probe_rows = max(1, 8 * 1024 * 1024 * 9 // (w * spp * max(9, len(spheres))))  # (a sample costs one test per sphere and bounce)
         t = time.perf_counter()
-        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=h // 2, row_end=h // 2 + probe_rows, threads=cores)
+        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=h // 2, row_end=h // 2 + probe_rows, threads=cores, max_bounces=mb)
         rate = probe_rows * w * spp / (time.perf_counter() - t)
         rows = int(max(probe_rows, min(h, 8.0 * rate / (w * spp))))
     r0 = h // 2 - rows // 2
@@ -72,7 +89,7 @@ def cpu_baseline(oracle, cfg, spheres, basis, rows):
 
     def timed(native):
         t = time.perf_counter()
-        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores, native=native)
+        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores, native=native, max_bounces=mb)
         return time.perf_counter() - t
 
     dt = timed(False)
@@ -150,6 +167,47 @@ def profile_records(pt, cfg_key, rng, ki):
     return recs[0], recs[1], why
 
 
+def other_configs(pt, torch, device, stream, rng_mode):
+    """Side record of the default run: the BASELINE.json configurations other than the headline on this one GPU --
+    cfg3 (4096^2 x 64 spp), cfg4 closed / open (1000 spheres, 1024^2 x 256 spp), and cfg5 as a stream of 200 frames
+    (512^2 x 4 spp x 8 bounces, enqueued back to back, one synchronisation at the end).  Kernel milliseconds are measured
+    with events on the launch stream; about two seconds of GPU time in total."""
+    out = {}
+    for key, warm, reps in (("cfg3", 1, 2), ("cfg4", 1, 2), ("cfg4open", 1, 2), ("cfg5", 5, 200)):
+        c = CONFIGS[key]
+        w, h, spp, mb = c["width"], c["height"], c["spp"], c["max_bounces"]
+        sph, label = scene_of(pt, c)
+        d_scene = torch.from_numpy(sph.view("u1").reshape(-1).copy()).to(device)
+        frame = torch.empty(h * w * 14, dtype=torch.float32, device=device)
+        basis = pt.camera_basis(width=w, height=h)
+        r = pt.Renderer(w, h, spp, rng_mode=rng_mode, persist_rng=True, max_bounces=mb)
+        for _ in range(warm):
+            r.enqueue(frame.data_ptr(), d_scene.data_ptr(), len(sph), basis, pt.DEFAULT_EYE, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(reps, 20))]
+        t0 = time.perf_counter()
+        for k in range(reps):
+            if k < len(ev):
+                ev[k][0].record(stream)
+            r.enqueue(frame.data_ptr(), d_scene.data_ptr(), len(sph), basis, pt.DEFAULT_EYE, stream=stream.cuda_stream)
+            if k < len(ev):
+                ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kms = sorted(a.elapsed_time(b) for a, b in ev)
+        ki = r.kernel_info(len(sph))
+        r.destroy()
+        samples = w * h * spp
+        out[key] = {"workload": f"{label} {w}x{h}, {spp} spp, max_bounces {mb} ({c['name']})", "frames": reps,
+                    "kernel_ms": round(kms[len(kms) // 2], 4), "kernel_ms_min": round(kms[0], 4),
+                    "wall_ms_per_frame": round(wall / reps * 1e3, 4),
+                    "Msamples_per_s": round(samples / (wall / reps) / 1e6, 1),
+                    "kernel_variant": ki["variant"], "num_vgprs": ki["num_vgprs"], "scratch_bytes": ki["scratch_bytes"],
+                    "hbm_algorithmic_GBps": round(56 * w * h / (kms[len(kms) // 2] * 1e-3) / 1e9, 2)}
+        del frame, d_scene
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +220,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (default: the library default)")
     ap.add_argument("--spp", type=int, default=None, help="override spp (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-rng", action="store_true", help="skip the extra philox measurement")
+    ap.add_argument("--no-alt-rng", action="store_true", help="skip the extra philox and fast-mode measurements")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the side record of the other BASELINE configurations")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = size for ~8 s per build)")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame to this .npy (tests)")
     args = ap.parse_args()
@@ -187,8 +246,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.spp is not None:
         cfg["spp"] = args.spp
-    WIDTH, HEIGHT, spp = cfg["width"], cfg["height"], cfg["spp"]
+    WIDTH, HEIGHT, spp, MAXB = cfg["width"], cfg["height"], cfg["spp"], cfg["max_bounces"]
     headline_config = args.spp is None
+    reference_scene = cfg["scene"] == "cornell" and MAXB == 5  # the alternative legs (philox, fast mode) are reported on these
 
     native = args.engine == "native"
     world = 1 if native else int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +279,7 @@ def main():
             dist.init_process_group(backend)
 
     rng_mode = pt.RNG_PHILOX if args.rng == "philox" else pt.RNG_XORWOW
-    spheres = pt.scene_cornell()
+    spheres, scene_label = scene_of(pt, cfg)
     basis = pt.camera_basis(width=WIDTH, height=HEIGHT)
     eye = pt.DEFAULT_EYE
     d_scene = torch.from_numpy(spheres.view("u1").reshape(-1).copy()).to(device)
@@ -233,7 +293,7 @@ def main():
         torch.cuda.synchronize()
 
         def measure(mode):
-            m = pt.MultiRenderer(devs, WIDTH, HEIGHT, spp, rng_mode=mode, variant=args.variant, persist_rng=True)
+            m = pt.MultiRenderer(devs, WIDTH, HEIGHT, spp, rng_mode=mode, variant=args.variant, persist_rng=True, max_bounces=MAXB)
             for _ in range(args.warmup):
                 m.render(frame.data_ptr(), d_scene.data_ptr(), len(spheres), basis, eye)
             k_ms = 0.0
@@ -248,7 +308,7 @@ def main():
         exchange = m.backend()
         rb, re_ = m.tile(0)["rows"]
         # a single-device renderer of rank 0's tile only to report which kernel that tile runs
-        probe = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=False)
+        probe = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=False, max_bounces=MAXB)
         ki = probe.kernel_info(len(spheres))
         probe.destroy()
         if args.dump:
@@ -257,6 +317,7 @@ def main():
             np.save(args.dump, frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
         alt = None
         fast = None
+        others = None
         m.destroy()
         tiling_note = f"rows/{n_gpus}, one process, {exchange}" if n_gpus > 1 else "single GPU (pt_mgpu_* with one device)"
     else:
@@ -269,7 +330,7 @@ def main():
         def measure(mode, fast_math=False):
             """W untimed + K timed frames with generator `mode`: (renderer, whole-job seconds, kernel seconds), max over ranks."""
             rend = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=mode, row_begin=rb, row_end=re_, variant=None if fast_math else args.variant,
-                               persist_rng=True, fast_math=fast_math)
+                               persist_rng=True, fast_math=fast_math, max_bounces=MAXB)
             pending = [[] for _ in fgs]
 
             def step(ev=None):
@@ -317,7 +378,7 @@ def main():
         # the same measurement with the counter-based generator (north star: "a counter-based RNG in registers
         # replacing curand"); reported beside the headline, which stays on the reference's XORWOW stream
         alt = None
-        if args.rng == "xorwow" and not args.no_alt_rng:
+        if args.rng == "xorwow" and not args.no_alt_rng and reference_scene:
             r2, e2, k2 = measure(pt.RNG_PHILOX)
             alt = {"rng": "philox4x32-10 (counter-based, no state traffic)", "value": round(total_samples / e2 / 1e6, 2),
                    "unit": "Msamples/s", "ms_per_step": round(e2 / args.steps * 1e3, 3), "kernel_ms": round(k2 * 1e3, 3),
@@ -326,7 +387,7 @@ def main():
         # the toleranced fast mode (FMA contraction, FP32-only intersect, hardware rsq/sin/cos; csrc/pt_fast.hip):
         # same workload, reported BESIDE the headline, which stays on the bit-exact kernel
         fast = None
-        if not args.no_alt_rng:
+        if not args.no_alt_rng and reference_scene:
             r3, e3, k3 = measure(rng_mode, fast_math=True)
             fast = {"mode": "fast_math=1: FMA contraction, FP32 cancellation-free intersect, v_rsq/v_sin/v_cos; NOT bit-exact",
                     "tolerance": "vs the exact kernel at equal seeds: per-channel image means within 4 standard errors of the MC mean; "
@@ -336,6 +397,11 @@ def main():
                     "kernel_ms": round(k3 * 1e3, 3), "rng": args.rng, "num_vgprs": r3.kernel_info(len(spheres))["num_vgprs"]}
             r3.destroy()
         tiling_note = f"rows/{world}, one process per GPU, gather to rank 0 ({backend} grouped isend/irecv)" if world > 1 else "single GPU"
+        # the other BASELINE.json configurations on this GPU (kernel time from events on the launch stream), after the headline
+        others = None
+        if world == 1 and args.config == "cfg2" and headline_config and not args.no_other_configs and args.variant is None:
+            renderer.destroy()
+            others = other_configs(pt, torch, device, stream, rng_mode)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -365,7 +431,7 @@ def main():
                                                       "took, both from the profiled run (tools/issue_model.py; the 1:2:4:8 ladder was "
                                                       "measured by tools/ubench/valu_clock)"}
         out = {
-            "metric": f"Msamples/s, 9-sphere Cornell box {WIDTH}x{HEIGHT}x{spp}spp",
+            "metric": f"Msamples/s, {scene_label} {WIDTH}x{HEIGHT}x{spp}spp" + ("" if MAXB == 5 else f", {MAXB} bounces"),
             "value": round(total_samples / elapsed / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": n_gpus,
@@ -376,9 +442,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32+f64",
-            "data": "synthetic (reference scene include/Scene.h:26-34, default camera, fixed seed)",
+            "data": "synthetic (reference scene include/Scene.h:26-34, default camera, fixed seed)" if cfg["scene"] == "cornell" else
+                    "synthetic (pt_scene_random: seeded spheres inside the reference's box, default camera, fixed seed)",
             "config": {
-                "workload": f"9-sphere Cornell box {WIDTH}x{HEIGHT}, {spp} spp, max_bounces 5, rng {args.rng} seed=pixel id ({cfg['name']})",
+                "workload": f"{scene_label} {WIDTH}x{HEIGHT}, {spp} spp, max_bounces {MAXB}, rng {args.rng} seed=pixel id ({cfg['name']})",
                 "tiling": tiling_note,
                 "engine": args.engine,
                 "kernel_variant": ki["variant"],
@@ -401,6 +468,7 @@ def main():
             "profile_stale": stale,
             "counter_based_rng": alt,
             "fast_mode": fast,
+            "other_configs": others,
             "kernel_info": dict(ki, fingerprint=pt.build_fingerprint()),
         }
         if n_gpus == 1 and not native and not args.no_cpu_baseline:

@@ -54,6 +54,8 @@ class RendererOpts(ctypes.Structure):
         ("variant", ctypes.c_int32),
         ("layout", ctypes.c_int32),
         ("fast_math", ctypes.c_int32),
+        ("chunks", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -324,7 +326,7 @@ class Renderer:
     """ctypes view of pt_renderer (the reference's class Renderer, include/Renderer.h)."""
 
     def __init__(self, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 row_begin=0, row_end=0, persist_rng=True, variant=None, layout=LAYOUT_INTERLEAVED, fast_math=False):
+                 row_begin=0, row_end=0, persist_rng=True, variant=None, layout=LAYOUT_INTERLEAVED, fast_math=False, chunks=0):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
@@ -332,6 +334,7 @@ class Renderer:
         o.persist_rng = 1 if persist_rng else 0
         o.layout = layout
         o.fast_math = 1 if fast_math else 0
+        o.chunks = chunks  # 0 automatic, 1 off, n >= 2 chunks
         if variant is not None:
             o.variant = variant
         self.variant = o.variant

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -50,8 +51,15 @@ struct pt_renderer {
   hipEvent_t ev_fail;
   bool fail_pending;
   uint32_t* d_accel;       // variant 11's grid tables (rebuilt on the device before every frame)
-  uint32_t* d_chunk;       // sample chunking (pt_kernel.hip): PT_CHUNK_WORDS words per tile pixel + one flag per pixel block; or null
+  uint32_t* d_chunk;       // sample chunking (pt_kernel.hip): PT_CHUNK_WORDS words per tile pixel + one flag per pixel block; allocated
+                           // by the first launch that chunks (never for renderers whose kernels do not), or null
   uint32_t chunks;         // how many chunks a frame of this renderer is split into when the kernel supports it (0 = off)
+  uint64_t chunk_wait_ticks;  // how long a chunk waits for its predecessor (wall-clock ticks of the device)
+  uint32_t* d_err;         // device error word (PT_DEVERR_*), raised by a kernel that could not go on correctly
+  uint32_t* h_err;         // pinned host copy, valid once ev_err has completed
+  hipEvent_t ev_err;
+  bool err_pending;        // a chunked launch's error word is on its way to h_err
+  uint32_t debug;          // PT_DEBUG_* (lab library only, env PT_LAB_DEBUG)
   // The renderer owns single-instance device scratch (generator state, d_accel, d_fail): launches of one
   // renderer must execute in submission order even when the caller alternates streams.
   hipEvent_t ev_last;      // recorded after every launch on the stream it went to
@@ -171,6 +179,7 @@ void pt_renderer_opts_default(pt_renderer_opts* o) {
   o->variant = PT_VARIANT_AUTO;
   o->layout = PT_LAYOUT_INTERLEAVED;
   o->fast_math = 0;
+  o->chunks = 0;
 }
 
 static int setup_random(pt_renderer* r) {
@@ -202,6 +211,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.fast_math != 0 && o.fast_math != 1) return pt_fail(PT_EINVAL, "pt_renderer_create: fast_math %d", o.fast_math);
   if (o.fast_math && o.variant != PT_VARIANT_AUTO)
     return pt_fail(PT_EINVAL, "pt_renderer_create: fast_math has one kernel; leave variant at -1");
+  if (o.chunks < 0 || o.chunks > PT_CHUNKS_MAX || o.reserved != 0)
+    return pt_fail(PT_EINVAL, "pt_renderer_create: chunks %d (0 = automatic, 1 = off, 2..%d), reserved %d (must be 0)", o.chunks, PT_CHUNKS_MAX, o.reserved);
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
     return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11; "
                               "the experiments 1-5, 7, 9, 12 live in libptcore_lab.so)", o.variant);
@@ -234,6 +245,12 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->d_accel = nullptr;
   r->d_chunk = nullptr;
   r->chunks = 0;
+  r->chunk_wait_ticks = 0;
+  r->d_err = nullptr;
+  r->h_err = nullptr;
+  r->ev_err = nullptr;
+  r->err_pending = false;
+  r->debug = 0;
   r->ev_last = nullptr;
   r->last_stream = nullptr;
   r->have_last = false;
@@ -253,18 +270,38 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (e == hipSuccess) { *r->h_fail = 0; e = hipEventCreateWithFlags(&r->ev_fail, hipEventDisableTiming); }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_accel, pt_kernel_accel_bytes());
   // Sample chunking pays on frames that make few rounds of long workgroups (tools/shape_sweep.py): at least 512 samples per
-  // pixel and at most 8 one-lane waves per SIMD slot-round.  The hand-over buffer is 112 B per tile pixel.
-  if (e == hipSuccess && r->spp >= 512 && r->tile_pixels > 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
-      const uint64_t slots = (uint64_t)prop.multiProcessorCount * 4u * 4u * 64u;  // pixels resident at 4 waves per SIMD
-      if ((uint64_t)r->tile_pixels <= 8u * slots) {
-        const size_t blocks = ((size_t)r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
-        e = hipMalloc((void**)&r->d_chunk, ((size_t)PT_CHUNK_WORDS * r->tile_pixels + blocks) * sizeof(uint32_t));
-        if (e == hipSuccess) r->chunks = PT_CHUNKS;
-      }
+  // pixel and at most 8 one-lane waves per SIMD slot-round.  opts.chunks / env PT_CHUNKS: 0 = this policy, 1 = never, n = n chunks.
+  // The hand-over buffer (104 B per tile pixel) is allocated by the first launch that really chunks (chunk_buffer()).
+  if (e == hipSuccess) {
+    int want = o.chunks;
+    if (want == 0) {
+      const char* env = getenv("PT_CHUNKS");
+      if (env && *env) want = atoi(env);
     }
+    if (want < 0 || want > PT_CHUNKS_MAX) want = 0;
+    hipDeviceProp_t prop;
+    if (want == 0 && r->spp >= 512 && r->tile_pixels > 0 && hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
+      const uint64_t slots = (uint64_t)prop.multiProcessorCount * 4u * 4u * 64u;  // pixels resident at 4 waves per SIMD
+      if ((uint64_t)r->tile_pixels <= 8u * slots) want = PT_CHUNKS;
+    }
+    // a chunk short enough that the worst chained wait stays far inside the wait limit: more chunks for very long frames
+    while (want >= 2 && want < PT_CHUNKS_MAX && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want *= 2;
+    if (want >= 2 && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want = 0;
+    r->chunks = want >= 2 ? (uint32_t)want : 0u;
+    int khz = 0;  // s_memrealtime ticks per millisecond
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
+    long wait_ms = 4000;
+    if (const char* env = getenv("PT_CHUNK_TIMEOUT_MS")) { if (*env) wait_ms = atol(env); }
+    if (wait_ms < 1) wait_ms = 1;
+    r->chunk_wait_ticks = (uint64_t)khz * (uint64_t)wait_ms;
+#if PT_BUILD_EXPERIMENTS
+    if (const char* env = getenv("PT_LAB_DEBUG")) r->debug = (uint32_t)strtoul(env, nullptr, 0);
+#endif
   }
+  if (e == hipSuccess) e = hipMalloc((void**)&r->d_err, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(r->d_err, 0, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_err, sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess) { *r->h_err = 0; e = hipEventCreateWithFlags(&r->ev_err, hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_last, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&r->ev_stop);
@@ -289,6 +326,9 @@ int pt_renderer_destroy(pt_renderer* r) {
   if (r->d_state) (void)hipFree(r->d_state);  // Renderer.h:50
   if (r->d_accel) (void)hipFree(r->d_accel);
   if (r->d_chunk) (void)hipFree(r->d_chunk);
+  if (r->d_err) (void)hipFree(r->d_err);
+  if (r->h_err) (void)hipHostFree(r->h_err);
+  if (r->ev_err) (void)hipEventDestroy(r->ev_err);
   if (r->d_fail) (void)hipFree(r->d_fail);
   if (r->h_fail) (void)hipHostFree(r->h_fail);
   if (r->ev_fail) (void)hipEventDestroy(r->ev_fail);
@@ -297,6 +337,39 @@ int pt_renderer_destroy(pt_renderer* r) {
   if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
   delete r;
   return PT_OK;
+}
+
+// Does a launch of this renderer with this variant and scene chain a pixel's samples through several workgroups?  Allocates the
+// hand-over buffer the first time the answer is yes; an allocation failure turns chunking off for good (it is a scheduling
+// aid, never a reason for a renderer not to work).
+static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {
+  if (r->chunks < 2u || !pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
+    return false;
+  if (r->d_chunk) return true;
+  const size_t blocks = ((size_t)r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
+  if (hipMalloc((void**)&r->d_chunk, ((size_t)PT_CHUNK_WORDS * r->tile_pixels + blocks) * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipGetLastError();  // not sticky: the launch that follows must not inherit it
+    r->d_chunk = nullptr;
+    r->chunks = 0;
+    return false;
+  }
+  return true;
+}
+
+// The error word of an earlier chunked launch: PT_EKERNEL once, and no more chunking for this renderer.
+static int check_device_error(pt_renderer* r, bool wait) {
+  if (!r->err_pending) return PT_OK;
+  if (wait) PT_HIP(hipEventSynchronize(r->ev_err));
+  else if (hipEventQuery(r->ev_err) != hipSuccess) { (void)hipGetLastError(); return PT_OK; }
+  r->err_pending = false;
+  const uint32_t err = *r->h_err;
+  if (err == 0u) return PT_OK;
+  *r->h_err = 0u;
+  (void)hipMemset(r->d_err, 0, sizeof(uint32_t));
+  r->chunks = 0;  // fall back to unchunked launches permanently: whatever broke the chain may do so again
+  return pt_fail(PT_EKERNEL, "render: sample-chunk chain broken (device error word 0x%x): a workgroup waited %.0f ms for its "
+                             "predecessor in vain; that frame is invalid, chunking is now off for this renderer", err,
+                 (double)r->chunk_wait_ticks / 1e5);
 }
 
 static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
@@ -328,9 +401,14 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->max_bounces = r->opts.max_bounces;
   a->frame = r->frame;
   a->seed = r->opts.seed;
-  a->chunks = r->chunks;  // the launcher keeps it only for the kernels that chunk (reference configuration, variant 6)
-  a->chunk_state = r->d_chunk;
-  a->chunk_flag = r->d_chunk ? r->d_chunk + (size_t)PT_CHUNK_WORDS * r->tile_pixels : nullptr;
+  // sample chunking: only for the kernels that chunk (reference configuration, variant 6), and only with a hand-over buffer
+  const bool chunking = variant != PT_VARIANT_FAST && chunk_buffer(r, variant, n_spheres);
+  a->chunks = chunking ? r->chunks : 0u;
+  a->chunk_state = chunking ? r->d_chunk : nullptr;
+  a->chunk_flag = chunking ? r->d_chunk + (size_t)PT_CHUNK_WORDS * r->tile_pixels : nullptr;
+  a->err_word = r->d_err;
+  a->chunk_wait_ticks = r->chunk_wait_ticks;
+  a->debug = r->debug;
   return PT_OK;
 }
 
@@ -348,6 +426,14 @@ static int watch_begin(pt_renderer* r, hipStream_t stream, bool* watching) {
   return PT_OK;
 }
 
+static int watch_error(pt_renderer* r, const PixelKernelArgs& a, hipStream_t stream) {
+  if (a.chunks < 2u) return PT_OK;  // only chunked launches can raise the word
+  PT_HIP(hipMemcpyAsync(r->h_err, r->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  PT_HIP(hipEventRecord(r->ev_err, stream));
+  r->err_pending = true;
+  return PT_OK;
+}
+
 static int watch_end(pt_renderer* r, hipStream_t stream, bool watching) {
   if (!watching) return PT_OK;
   PT_HIP(hipMemcpyAsync(r->h_fail, r->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -359,7 +445,10 @@ static int watch_end(pt_renderer* r, hipStream_t stream, bool watching) {
 int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
                         const float eye[3], void* hip_stream) {
   PixelKernelArgs a;
-  int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
+  if (!r) return pt_fail(PT_EINVAL, "render: renderer is NULL");
+  int rc = check_device_error(r, false);  // an earlier asynchronous frame whose chain broke is reported here
+  if (rc != PT_OK) return rc;
+  rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
   if (rc != PT_OK) return rc;
   if (r->tile_pixels == 0) return PT_OK;
   rc = order_after_last(r, (hipStream_t)hip_stream);
@@ -370,6 +459,8 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
   PT_HIP(launch(r, a, (hipStream_t)hip_stream));
   rc = watch_end(r, (hipStream_t)hip_stream, watching);
   if (rc != PT_OK) return rc;
+  rc = watch_error(r, a, (hipStream_t)hip_stream);
+  if (rc != PT_OK) return rc;
   rc = mark_last(r, (hipStream_t)hip_stream);
   if (rc != PT_OK) return rc;
   r->frame++;
@@ -379,7 +470,10 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
 int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
                        const float eye[3], float* ms_out) {
   PixelKernelArgs a;
-  int rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
+  if (!r) return pt_fail(PT_EINVAL, "render: renderer is NULL");
+  int rc = check_device_error(r, true);
+  if (rc != PT_OK) return rc;
+  rc = fill_args(r, d_out, d_spheres, n_spheres, basis, eye, &a);
   if (rc != PT_OK) return rc;
   if (ms_out) *ms_out = 0.0f;
   if (r->tile_pixels == 0) return PT_OK;
@@ -393,13 +487,15 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   PT_HIP(hipEventRecord(r->ev_stop, nullptr));   // Renderer.h:70
   rc = watch_end(r, nullptr, watching);
   if (rc != PT_OK) return rc;
+  rc = watch_error(r, a, nullptr);
+  if (rc != PT_OK) return rc;
   PT_HIP(hipEventSynchronize(r->ev_stop));       // Renderer.h:72
   r->have_last = false;  // the launch has completed: nothing left to order against
   r->frame++;
   float ms = 0.0f;
   PT_HIP(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
   if (ms_out) *ms_out = ms;
-  return PT_OK;
+  return check_device_error(r, true);  // a synchronous frame whose chain broke is an error of THIS call
 }
 
 int pt_renderer_set_frame(pt_renderer* r, uint32_t frame) {
@@ -445,7 +541,7 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->variant = variant;
   if (variant == 8 || variant == 9)
     info->grid_blocks = (int)(((uint64_t)r->tile_pixels * (variant == 8 ? 4 : 2) + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-  if (!fast && r->d_chunk && pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
+  if (!fast && r->chunks >= 2u && pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
     info->grid_blocks *= (int)r->chunks;  // sample chunking: that many workgroups per pixel block
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;

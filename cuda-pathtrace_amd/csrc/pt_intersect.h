@@ -574,7 +574,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);
   int i = 0;
   if constexpr (PRIMARY && P == 1) {  // rank only the spheres the wave's pixel footprints leave (pt_footprint.h)
-    const uint32_t full = (1u << n) - 1u;
+    const uint32_t full = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
     uint32_t m = __builtin_amdgcn_readfirstlane(sc.prim_mask) & full;
     if (n <= 16 && m != full) {
       while (m) {

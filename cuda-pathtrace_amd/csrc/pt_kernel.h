@@ -97,11 +97,22 @@ struct PixelKernelArgs {
   uint32_t chunks;             // 0 or 1 = off
   uint32_t* chunk_state;       // PT_CHUNK_WORDS words per tile pixel, [word][pixel]
   uint32_t* chunk_flag;        // per pixel block: number of chunks completed (zeroed before the launch)
+  uint32_t* err_word;          // device error word of the renderer (PT_DEVERR_*), OR-ed into by a kernel that cannot go on correctly
+  uint64_t chunk_wait_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) a chunk waits for its predecessor before it gives up
+  uint32_t debug;              // lab library only (PT_DEBUG_*): deliberate faults for the failure-path tests
 };
-#define PT_CHUNK_WORDS 28
+// words handed from one chunk of a pixel block to the next: 10 sums, 2 counts (colour; the three first-hit accumulators share
+// one), 4 x {mean, M2}, and the 6 generator words (xorwow only; philox needs none)
+#define PT_CHUNK_WORDS 26
 #ifndef PT_CHUNKS
 #define PT_CHUNKS 8
 #endif
+#define PT_CHUNKS_MAX 16
+// A chunk may only be as long as keeps the worst chained wait (all chunks of a block co-resident: chunk k waits k chunk
+// durations) far inside the wait limit: at most this many samples per chunk (about 50 ms of kernel time on an MI355X)
+#define PT_CHUNK_MAX_SAMPLES 4096
+#define PT_DEVERR_CHUNK_CHAIN 1u  // a chunk's predecessor never signalled: the frame is invalid
+#define PT_DEBUG_DROP_CHUNK_FLAG 1u  // pixel block 0, chunk 0 does not publish its flag (tests/test_chunk_chain_gpu.py)
 
 #ifndef PT_BUILD_EXPERIMENTS
 #define PT_BUILD_EXPERIMENTS 0  // 1: also build variants 1-5, 7, 9, 12 (libptcore_lab.so)

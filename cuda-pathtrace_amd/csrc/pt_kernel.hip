@@ -41,9 +41,12 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
 
   // Sample chunking (REF builds of variant 6): workgroup blockIdx.x = chunk * n_blocks + block renders samples
   // [chunk * per, (chunk + 1) * per) of its 256 pixels and hands generator, sums and Welford accumulators to the next chunk
-  // through chunk_state.  Workgroups are dispatched in index order, so the predecessor of a waiting workgroup is resident or
-  // done -- it never waits for anything itself -- and the wait cannot deadlock.  Same operations per pixel in the same order;
-  // what changes is that a frame of few, long workgroups becomes one of many short ones (tools/shape_sweep.py: why).
+  // through chunk_state.  Forward progress ("sample chunking"): every dispatcher hands out its workgroups in
+  // increasing index order, so by induction on the lowest unfinished index the predecessor of a waiting workgroup is resident
+  // or done -- and the lowest unfinished one never waits.  That is a property of today's hardware, not of the programming
+  // model, so the wait is bounded in time and giving up raises the renderer's error word (PT_EKERNEL), never a silent frame.
+  // Same operations per pixel in the same order; what changes is that a frame of few, long workgroups becomes one of many
+  // short ones (tools/shape_sweep.py: why).
   uint32_t block_id = blockIdx.x, chunk = 0u, n_chunks = 1u;
   if constexpr (REF && VAR == 6) {
     if (a.chunks > 1u) {
@@ -89,10 +92,17 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       i_end = i_begin + per < a.spp ? i_begin + per : a.spp;
       if (chunk > 0u) {
         if (threadIdx.x == 0) {  // wait for the previous chunk of this pixel block
+          // The wait is bounded in TIME (s_memrealtime), and giving up is an ERROR the host reports (PT_EKERNEL), never a
+          // silent frame: the waiter raises the renderer's device error word, goes on with whatever the hand-over buffer
+          // holds and still publishes its own flag, so that its successors do not each wait out the limit as well.
+          const uint64_t t0 = wall_clock64();
           uint32_t spins = 0;
           while (__hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 20)) break;  // ~1 s: never reached unless the launch is broken (the tests would see the image)
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > a.chunk_wait_ticks) {
+              if (a.err_word) atomicOr(a.err_word, PT_DEVERR_CHUNK_CHAIN);
+              break;
+            }
           }
         }
         __syncthreads();
@@ -103,9 +113,10 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
           L.normal = mk3(ldf(3), ldf(4), ldf(5));
           L.albedo = mk3(ldf(6), ldf(7), ldf(8));
           L.depth = ldf(9);
+          const int n0 = (int)ld(10), n1 = (int)ld(11);  // the three first-hit accumulators count together (welford_update3)
 #pragma unroll
-          for (int k = 0; k < 4; k++) var[k] = Welford{(int)ld(10 + 3 * k), ldf(11 + 3 * k), ldf(12 + 3 * k)};
-          if constexpr (RNG == PT_RNG_XORWOW) rng.st = Xorwow{ld(22), ld(23), ld(24), ld(25), ld(26), ld(27)};
+          for (int k = 0; k < 4; k++) var[k] = Welford{k == 0 ? n0 : n1, ldf(12 + 2 * k), ldf(13 + 2 * k)};
+          if constexpr (RNG == PT_RNG_XORWOW) rng.st = Xorwow{ld(20), ld(21), ld(22), ld(23), ld(24), ld(25)};
         }
       }
     }
@@ -327,19 +338,23 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
         stf(3, L.normal.x); stf(4, L.normal.y); stf(5, L.normal.z);
         stf(6, L.albedo.x); stf(7, L.albedo.y); stf(8, L.albedo.z);
         stf(9, L.depth);
+        st(10, (uint32_t)var[0].n);
+        st(11, (uint32_t)var[1].n);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          st(10 + 3 * k, (uint32_t)var[k].n);
-          stf(11 + 3 * k, var[k].mean);
-          stf(12 + 3 * k, var[k].M2);
+          stf(12 + 2 * k, var[k].mean);
+          stf(13 + 2 * k, var[k].M2);
         }
         if constexpr (RNG == PT_RNG_XORWOW) {
-          st(22, rng.st.d); st(23, rng.st.v0); st(24, rng.st.v1); st(25, rng.st.v2); st(26, rng.st.v3); st(27, rng.st.v4);
+          st(20, rng.st.d); st(21, rng.st.v0); st(22, rng.st.v1); st(23, rng.st.v2); st(24, rng.st.v3); st(25, rng.st.v4);
         }
       }
       __syncthreads();  // every wave's stores are issued ...
       if (threadIdx.x == 0) {
         __threadfence();  // ... and visible device-wide before the flag says so
+#if PT_BUILD_EXPERIMENTS  // lab library: a deliberately broken chain for the failure-path test
+        if (!((a.debug & PT_DEBUG_DROP_CHUNK_FLAG) && block_id == 0u && chunk == 0u))
+#endif
         __hip_atomic_store(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
       return;
@@ -771,7 +786,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 // does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
   return variant == 6 && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar) && chunks > 1u &&
-         spp >= 2 * (int)chunks;
+         chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks && (spp + (int)chunks - 1) / (int)chunks <= PT_CHUNK_MAX_SAMPLES;
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {

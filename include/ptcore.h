@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 enum {
   PT_OK = 0,
@@ -43,7 +43,9 @@ enum {
   PT_ENOMEM = -4,    /* host allocation failed                               */
   PT_ELIMIT = -5,    /* scene does not fit the kernel's LDS staging budget   */
   PT_ECOMM = -6,     /* RCCL could not be loaded or a collective call failed (multi-GPU) */
-  PT_ETIMEOUT = -7   /* a multi-GPU frame did not complete in time; the exchange was aborted */
+  PT_ETIMEOUT = -7,  /* a multi-GPU frame did not complete in time; the exchange was aborted */
+  PT_EKERNEL = -8    /* the kernel itself reported a failure (sample-chunk chain broken): the frame it wrote is */
+                     /*   NOT valid; the renderer has switched sample chunking off and later frames are good   */
 };
 
 /* struct Sphere, include/Scene.h:7-14 -- same 40-byte layout, so a reference
@@ -82,6 +84,11 @@ typedef struct pt_renderer_opts {
                         /*   generator streams, FMA contraction allowed (nvcc's default for the reference), FP32-only   */
                         /*   cancellation-free intersectSphere, hardware rsq/sin/cos.  Results agree with the exact   */
                         /*   kernels statistically, not bitwise (tolerances: tests/test_fast_mode_gpu.py).           */
+  int32_t chunks;       /* sample chunking (scheduling only, same bits): 0 (default) = automatic -- long frames of few   */
+                        /*   workgroups split every pixel block's samples over several chained workgroups of one launch */
+                        /*   (kernel map); 1 = never; 2..16 = that many chunks where the kernel supports it. */
+                        /*   Costs scratch HBM (104 B per tile pixel) and hand-over traffic.  Env PT_CHUNKS overrides 0. */
+  int32_t reserved;     /* must be 0 */
 } pt_renderer_opts;
 
 typedef struct pt_renderer pt_renderer; /* opaque; replaces class Renderer's private state, Renderer.h:10-20 */

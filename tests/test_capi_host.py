@@ -42,9 +42,9 @@ def test_product_library_is_lean_and_the_lab_library_is_a_superset(pt, lab):
 
 
 def test_abi_version_and_struct_layout(pt):
-    assert pt.lib.pt_abi_version() == 3
+    assert pt.lib.pt_abi_version() == 4
     assert pt.SPHERE_DTYPE.itemsize == 40          # include/Scene.h:7-14
-    assert ctypes.sizeof(pt.RendererOpts) == 40 and ctypes.sizeof(pt.MgpuOpts) == 16
+    assert ctypes.sizeof(pt.RendererOpts) == 48 and ctypes.sizeof(pt.MgpuOpts) == 16
     o = pt.RendererOpts()
     pt.lib.pt_renderer_opts_default(ctypes.byref(o))
     assert (o.max_bounces, o.rng_mode, o.seed, o.persist_rng, o.variant, o.layout) == (5, 0, 0, 1, -1, pt.LAYOUT_INTERLEAVED)

@@ -1,0 +1,77 @@
+"""Sample chunking must fail LOUDLY: a workgroup whose predecessor never signals raises the renderer's device error word,
+the call returns PT_EKERNEL (never PT_OK with a wrong frame), and the renderer goes on unchunked -- bit-exact again.
+The broken chain is provoked in the lab library (PT_LAB_DEBUG=1: pixel block 0, chunk 0 does not publish its flag)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PT_EKERNEL = -8
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_chunk_switch_and_lazy_buffer(pt, gpu, oracle):
+    """opts.chunks: 1 = never, n = n chained workgroups per pixel block, 0 = automatic; the bits do not depend on it."""
+    w, h, spp = 40, 24, 601
+    basis = pt.camera_basis(width=w, height=h)
+    ref = oracle.render(w, h, spp, spheres=pt.scene_cornell(), basis=basis)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(w * h * 56)
+    blocks = (w * h + 255) // 256
+    for chunks, per_block in ((1, 1), (2, 2), (4, 4), (8, 8), (16, 16), (0, 8)):
+        r = pt.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=chunks)
+        assert r.kernel_info(n)["grid_blocks"] == blocks * per_block, chunks
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref)), f"chunks={chunks}"
+        r.destroy()
+    # kernels that never chunk report one workgroup per pixel block whatever the option says
+    r = pt.Renderer(w, h, spp, variant=8, chunks=8)
+    assert r.kernel_info(n)["grid_blocks"] == (w * h * 4 + 255) // 256
+    r.destroy()
+    with pytest.raises(pt.PtError) as e:
+        pt.Renderer(w, h, spp, chunks=17)
+    assert e.value.code == -1
+
+
+def test_broken_chunk_chain_is_an_error_not_a_frame(lab, gpu, oracle):
+    w, h, spp = 64, 16, 640
+    basis = lab.camera_basis(width=w, height=h)
+    ref = oracle.render(w, h, spp, spheres=lab.scene_cornell(), basis=basis)
+    d_scene, n = lab.upload_scene(lab.scene_cornell())
+    d_out = lab.DeviceBuffer(w * h * 56)
+    old = {k: os.environ.get(k) for k in ("PT_LAB_DEBUG", "PT_CHUNK_TIMEOUT_MS")}
+    os.environ["PT_LAB_DEBUG"] = "1"
+    os.environ["PT_CHUNK_TIMEOUT_MS"] = "150"
+    try:
+        r = lab.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=4)   # synchronous Render(): the error belongs to this call
+        r2 = lab.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=4)  # enqueue: reported by the next call on the renderer
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert r.kernel_info(n)["grid_blocks"] == 4 * ((w * h + 255) // 256)
+    with pytest.raises(lab.PtError) as e:
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == PT_EKERNEL and "chunk" in str(e.value)
+    # the renderer has stopped chunking: one workgroup per pixel block, and the frame is the oracle's again
+    assert r.kernel_info(n)["grid_blocks"] == (w * h + 255) // 256
+    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref))
+    r.destroy()
+
+    r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)
+    lab.check(lab.lib.pt_device_synchronize())
+    with pytest.raises(lab.PtError) as e:
+        r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == PT_EKERNEL
+    r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)  # unchunked from here on
+    lab.check(lab.lib.pt_device_synchronize())
+    assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref))
+    r2.destroy()
