@@ -228,6 +228,10 @@ def main():
 
     if args.gpus > 1 and args.engine == "dist" and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))  # before anything here touches the GPU
+    if os.environ.get("PT_BENCH_TEST_PIDDIR"):  # tests/test_bench_multirank_gpu.py: which processes a job consisted of ...
+        open(os.path.join(os.environ["PT_BENCH_TEST_PIDDIR"], str(os.getpid())), "w").close()
+    if os.environ.get("PT_BENCH_TEST_DIE_RANK") == os.environ.get("RANK", "0") and "WORLD_SIZE" in os.environ:
+        os._exit(17)  # ... and a rank that dies before its first frame
 
     # stdout carries ONE JSON line and nothing else: libraries that print to file descriptor 1 on their own (RCCL writes a
     # version banner there when a communicator is created) are pointed at stderr until the line is printed
@@ -248,7 +252,7 @@ def main():
         cfg["spp"] = args.spp
     WIDTH, HEIGHT, spp, MAXB = cfg["width"], cfg["height"], cfg["spp"], cfg["max_bounces"]
     headline_config = args.spp is None
-    reference_scene = cfg["scene"] == "cornell" and MAXB == 5  # the alternative legs (philox, fast mode) are reported on these
+    reference_scene = cfg["scene"] == "cornell"  # the alternative legs (philox, fast mode) are reported on the reference's scene
 
     native = args.engine == "native"
     world = 1 if native else int(os.environ.get("WORLD_SIZE", "1"))

@@ -159,7 +159,7 @@ def variants():
     """Kernel variants compiled into the loaded library (product: 0, 6, 8, 10, 11; lab: 0..12)."""
     out = []
     o = RendererOpts()
-    for v in range(13):
+    for v in range(14):
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.variant = v
         h = _vp()

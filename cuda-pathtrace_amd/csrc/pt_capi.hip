@@ -214,7 +214,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.chunks < 0 || o.chunks > PT_CHUNKS_MAX || o.reserved != 0)
     return pt_fail(PT_EINVAL, "pt_renderer_create: chunks %d (0 = automatic, 1 = off, 2..%d), reserved %d (must be 0)", o.chunks, PT_CHUNKS_MAX, o.reserved);
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
-    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11; "
+    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11, 13; "
                               "the experiments 1-5, 7, 9, 12 live in libptcore_lab.so)", o.variant);
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");

@@ -36,11 +36,14 @@
 
 namespace pt {
 
+// Grid resolution.  Round 3, with the sphere tests pooled (variant 13) a test costs a 64th of a pass and the balance moved
+// towards finer cells: 1000 spheres + walls at 32 spp, cells per sphere 0.5 / 1 / 2 / 3 / 4: 15.3 / 14.0 / 13.9 / 13.6 / 13.0 ms at
+// six waves per SIMD, 3: 12.7 and 4: 13.0 at four (profiles/r03/cfg4_ab.txt); variant 11 is indifferent (16.6-16.7 ms).
 #ifndef PT_GRID_MAX_CELLS
-#define PT_GRID_MAX_CELLS 2048
+#define PT_GRID_MAX_CELLS 4096
 #endif
 #ifndef PT_GRID_CELLS_PER_SPHERE
-#define PT_GRID_CELLS_PER_SPHERE 2.0f
+#define PT_GRID_CELLS_PER_SPHERE 3.0f
 #endif
 constexpr int kGridMaxCells = PT_GRID_MAX_CELLS;
 #ifndef PT_GRID_TESTS_PER_TRIP
@@ -382,10 +385,21 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
 // [0] walks (wave level), [1] test trips, [2] lanes testing summed over trips, [3] step rounds, [4] lanes stepping summed
 // over rounds, [5] lanes that entered the walk, [6] ambiguous lanes (literal loop)
 __device__ unsigned long long g_grid_stats[8];
+// histograms: [0] sphere tests per ray, [1] cell steps per ray, [2] test trips per wave walk, [3] step rounds per wave walk (bucket 63 = 63 and more)
+__device__ unsigned long long g_grid_hist[4][64];
+#define PT_HIST_DECL int hist_tests = 0, hist_steps = 0, hist_trips = 0, hist_rounds = 0
+#define PT_HIST_LANE(var, n) do { var += (n); } while (0)
+#define PT_HIST_END(in_walk) do { \
+    if (in_walk) { atomicAdd(&g_grid_hist[0][hist_tests < 63 ? hist_tests : 63], 1ull); atomicAdd(&g_grid_hist[1][hist_steps < 63 ? hist_steps : 63], 1ull); } \
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) { \
+      atomicAdd(&g_grid_hist[2][hist_trips < 63 ? hist_trips : 63], 1ull); atomicAdd(&g_grid_hist[3][hist_rounds < 63 ? hist_rounds : 63], 1ull); } } while (0)
 #define PT_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); /* evaluated by the whole wave */ \
     if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_grid_stats[i], v_); } while (0)
 #else
 #define PT_STAT(i, v) do { } while (0)
+#define PT_HIST_DECL
+#define PT_HIST_LANE(var, n) do { } while (0)
+#define PT_HIST_END(in_walk) do { } while (0)
 #endif
 #ifdef PT_GRID_STATS_AMBIG
 #define PT_STATW(i, v) do { } while (0)   // the walk's own counters make room for the reasons
@@ -592,6 +606,7 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
   const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
   uint32_t left = walk.left, k0 = walk.k0, k1 = walk.k1, n0 = walk.n0, n1 = walk.n1;
   bool have_next = walk.have_next, walking = walk.walking;
+  PT_HIST_DECL;
   for (;;) {
     // Stepping is done one cell AHEAD and for the whole wave at once: a round is triggered only when some lane has used
     // up its list and has no next one in hand, and in that round EVERY lane without a next list takes its step.  (One
@@ -608,7 +623,9 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
       const bool step = in_walk & walking & !have_next;
       PT_STATW(3, 1);
       PT_STATW(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(step)));
+      PT_HIST_LANE(hist_rounds, 1);
       if (step) {
+        PT_HIST_LANE(hist_steps, 1);
         const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
         const float reach = (t_exit - slack_t) * two_a;
         // nothing that could still matter lies beyond the cell being left: stop (same rule as before)
@@ -637,7 +654,9 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
     }
     PT_STATW(1, 1);
     PT_STATW(2, __builtin_popcountll(testing_mask));
+    PT_HIST_LANE(hist_trips, 1);
     if (testing) {
+      PT_HIST_LANE(hist_tests, (int)((k1 - k0) < 3u ? (k1 - k0) : 3u));
       // (Measured and dropped: requesting the NEXT trip's two indices before the tests, to take one LDS latency off the
       // chain -- 3 % slower: the extra selects and the stale-list check cost more than the latency six waves already hide.)
       // Up to three registered spheres per trip, as many as the list has left: index and geometry reads of all of them are
@@ -669,6 +688,7 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
 #endif
     }
   }
+  PT_HIST_END(in_walk);
   walk.s = s;
   walk.tmax0 = tmax0, walk.tmax1 = tmax1, walk.tmax2 = tmax2;
   walk.cidx = cidx;
@@ -732,6 +752,223 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
     const bool admitted = grid_admits(G, o, d, a);
     PT_STATW(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);  // waves that also run the brute-force loop
     if (admitted) return intersect_scene_grid(sc, G, n, o, d, a, t_hit, idx);
+  }
+  return intersect_scene_screened_large(sc, n, o, d, make_ray_const(d), t_hit, idx);
+}
+
+// ---- variant 13: the grid walk with the sphere tests POOLED across the lanes of the wave ---------------------------------
+// Variant 11's walk is divergent: a ray needs 12 sphere tests on average but one ray in a hundred needs 55, so a wave makes
+// 21 test trips (up to three tests each) with 17 of its 64 lanes testing -- and the tests are two thirds of the kernel's
+// instructions (tools/grid_stats.py, profiles/r03).  Here a lane does not test its own spheres.  Rays, accumulators and
+// generators stay in their lanes (a pixel's float sums are order-sensitive); what moves is the WORK:
+//  * a lane that steps into a cell appends that cell's registered spheres to a per-wave LDS ring as (owner lane, sphere)
+//    entries -- slots from a ballot and v_mbcnt prefix per list position, no atomics, no scan;
+//  * whenever the ring holds a wave's worth, all 64 lanes drain it: lane r takes entry head + r, fetches the OWNER's ray with
+//    ds_bpermute (the wave64 __shfl), runs the same float screen near2_test runs, and returns a hit to the owner's slot
+//    with LDS atomics on integer keys: key = (estimate's float bits << 32) | sphere index, best = ds_min_u64, and the
+//    loser of each exchange goes to the runner-up slot with ds_min_u32.  Best and runner-up are the two smallest elements
+//    of the MULTISET of tested keys, so they do not depend on the order in which the wave happened to test them; equal keys
+//    are the same sphere met in two cells and are entered once (what near2_test's leader check does);
+//  * the owner reads its best estimate back (one ds_read) when it evaluates the stop rule of its next step.  That value
+//    may be stale by the entries still in the ring: the rule then fires later, never earlier -- more cells, more tests, the
+//    same superset argument as the look-ahead step of variant 11 (exactness appendix A.6 (iii-b)).
+// Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
+// expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
+// (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
+constexpr int kPoolRing = 256;  // ring entries per wave: a round adds at most 64 * kPoolPush to fewer than 64 pending
+#ifndef PT_POOL_PUSH
+#define PT_POOL_PUSH 3
+#endif
+constexpr int kPoolPush = PT_POOL_PUSH;
+static_assert(64 * kPoolPush + 63 < kPoolRing + 1, "pool ring too small");
+constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4;  // ring, best keys, runner-up estimates
+
+struct PoolLds {
+  uint32_t* ring;            // [kPoolRing] (owner lane << 16) | sphere index
+  unsigned long long* key1;  // [64] per owner lane: (bits of the smallest estimate << 32) | its sphere
+  uint32_t* t2;              // [64] per owner lane: bits of the second smallest estimate
+};
+constexpr unsigned long long kPoolEmpty = 0x7F800000FFFFFFFFull;  // +inf, no sphere
+
+__device__ __forceinline__ PoolLds pool_of_wave(void* workgroup_base) {
+  char* b = reinterpret_cast<char*>(workgroup_base) + (threadIdx.x >> 6) * kPoolWaveBytes;
+  PoolLds p;
+  p.key1 = reinterpret_cast<unsigned long long*>(b);
+  p.ring = reinterpret_cast<uint32_t*>(b + 64 * 8);
+  p.t2 = reinterpret_cast<uint32_t*>(b + 64 * 8 + kPoolRing * 4);
+  return p;
+}
+
+#ifdef PT_GRID_STATS
+#define PT_POOL_STAT(i, v) PT_STAT(i, v)
+#else
+#define PT_POOL_STAT(i, v) do { } while (0)
+#endif
+
+__device__ __forceinline__ float bperm_f(int byte_addr, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// The walk of variant 13 (between grid_begin and grid_end).  Every lane that is in the function helps testing; `walk`
+// belongs to the lane's own ray (walk.walking false and an empty list: a ray that misses the grid box).
+__device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds& G, const PoolLds& P, F3 o, F3 d) {
+  const float INF = __builtin_inff();
+  const int lane = threadIdx.x & 63;
+  const float two_a = 2.0f * walk.a, a4 = 4.0f * walk.a;
+  const float Tlim_hi = 1000000.0f * two_a * 1.0000153f;
+  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
+  float tmax0 = walk.tmax0, tmax1 = walk.tmax1, tmax2 = walk.tmax2;
+  const float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
+  int cidx = walk.cidx;
+  const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
+  uint32_t left = walk.left, k0 = walk.k0, k1 = walk.k1;
+  bool walking = walk.walking;
+  // lanes of this wave that are here (the others are on the brute-force path, or their pixel is finished): ranks, not lane
+  // numbers, index the ring
+  const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+  const uint32_t n_here = (uint32_t)__builtin_popcountll(here);
+  // what the spheres outside the grid (grid_begin) left: the owner's slots
+  // (every access to the slots is an atomic one: they are written by whichever lanes draw the owner's entries)
+  __hip_atomic_store(P.key1 + lane, walk.s.T1 < INF ? (((unsigned long long)__float_as_uint(walk.s.T1) << 32) | (uint32_t)walk.s.i1) : kPoolEmpty,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_store(P.t2 + lane, __float_as_uint(walk.s.T2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  uint32_t head = 0u, tail = 0u;  // wave-uniform ring positions (slot = position mod kPoolRing)
+  float T1 = walk.s.T1;           // the owner's best estimate as of the last drain (read back at the end of every round)
+  PT_HIST_DECL;
+  for (;;) {
+    // (1) one step for every lane whose list is used up
+    const bool need = walking & (k0 >= k1);
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      PT_STATW(3, 1);
+      PT_STATW(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(need)));
+      PT_HIST_LANE(hist_rounds, 1);
+      if (need) {
+        PT_HIST_LANE(hist_steps, 1);
+        const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
+        const float reach = (t_exit - slack_t) * two_a;
+        const bool stop = (T1 * 1.0000077f < reach) | (reach > Tlim_hi);
+        const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
+        const bool a1 = !a0 & (tmax1 <= tmax2);
+        tmax0 = a0 ? tmax0 + tdel0 : tmax0;
+        tmax1 = a1 ? tmax1 + tdel1 : tmax1;
+        tmax2 = (a0 | a1) ? tmax2 : tmax2 + tdel2;
+        cidx += a0 ? cs0 : (a1 ? cs1 : cs2);
+        left -= a0 ? 1u : (a1 ? (1u << 10) : (1u << 20));
+        walking = !stop & ((left & 0x20080200u) == 0x20080200u);
+        if (walking) {
+          k0 = G.cell_start[cidx];
+          k1 = G.cell_start[cidx + 1];
+        }
+      }
+    }
+    // (2) append up to kPoolPush spheres of every lane's list to the ring
+    const uint32_t c = k0 < k1 ? ((k1 - k0) < (uint32_t)kPoolPush ? (k1 - k0) : (uint32_t)kPoolPush) : 0u;
+    const bool any_list = __builtin_amdgcn_ballot_w64(c != 0u) != 0;
+    const bool any_walking = __builtin_amdgcn_ballot_w64(walking) != 0;
+    if (any_list) {
+      PT_HIST_LANE(hist_tests, (int)c);
+      uint32_t it[kPoolPush];
+#pragma unroll
+      for (int j = 0; j < kPoolPush; j++) it[j] = G.items[(uint32_t)j < c ? k0 + (uint32_t)j : 0u];  // all reads first
+      // ring positions: a lane's entries are consecutive, starting at the exclusive prefix sum of c over the lanes, which two
+      // ballots give (c = c0 + 2 c1 <= 3): prefix = mbcnt(ballot(c0)) + 2 mbcnt(ballot(c1))
+      static_assert(kPoolPush <= 3, "the prefix below sums two count bits");
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64((c & 1u) != 0u), m1 = __builtin_amdgcn_ballot_w64((c & 2u) != 0u);
+      const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+      const uint32_t p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+      const uint32_t pos = tail + p0 + 2u * p1;
+      const uint32_t tag = (uint32_t)lane << 16;
+#pragma unroll
+      for (int j = 0; j < kPoolPush; j++)
+        if (c > (uint32_t)j) P.ring[(pos + (uint32_t)j) & (uint32_t)(kPoolRing - 1)] = tag | it[j];
+      tail += (uint32_t)__builtin_popcountll(m0) + 2u * (uint32_t)__builtin_popcountll(m1);
+      k0 += c;
+    }
+    // (3) drain: whole passes while the ring holds one; everything once nobody can add to it any more
+    const bool last = !any_list & !any_walking;
+    while ((tail - head) >= (last ? 1u : n_here)) {
+      const uint32_t n = (tail - head) < n_here ? (tail - head) : n_here;
+      const bool valid = rank < n;
+      PT_STATW(1, 1);
+      PT_STATW(2, n);
+      PT_HIST_LANE(hist_trips, 1);
+      const uint32_t e = P.ring[(head + rank) & (uint32_t)(kPoolRing - 1)];
+      head += n;
+      const int owner = valid ? (int)(e >> 16) : lane;
+      const int i = valid ? (int)(e & 0xFFFFu) : 0;
+      const float4 g = G.geom[i];
+      const int oa = owner << 2;
+      const F3 ro = mk3(bperm_f(oa, o.x), bperm_f(oa, o.y), bperm_f(oa, o.z));
+      const F3 rd = mk3(bperm_f(oa, d.x), bperm_f(oa, d.y), bperm_f(oa, d.z));
+      const float ra4 = bperm_f(oa, a4);
+      const float rTlim_hi = 1000000.0f * (0.5f * ra4) * 1.0000153f;  // the owner's own Tlim_hi: same operands, same operations
+      // the float screen of near2_test
+      const F3 off = mk3(ro.x - g.x, ro.y - g.y, ro.z - g.z);
+      const float b = 2.0f * dot(rd, off);
+      const float cc = dot(off, off) - g.w;
+      const float bb = b * b;
+      const float a4c = ra4 * cc;
+      const float dacc = fmaf(-ra4, cc, bb);
+      const bool cand = valid & ((int)__float_as_uint(dacc) >= 0);
+      const float sq = __builtin_amdgcn_sqrtf(dacc);
+      const float q = b + copysignf(sq, b);
+      const float ee = fmaf(b, b, -bb);
+      const float num = a4c + ee;
+      const float TA = -q;
+      const float TB = -num * __builtin_amdgcn_rcpf(q);
+      const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(cc) & 0x80000000u));
+      float T = __builtin_amdgcn_fmed3f(TA, TB, K);
+      const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);
+      bool ok = cand & sure & ((int)__float_as_uint(T) >= 0) & (T < rTlim_hi);
+      if (__builtin_expect(cand & !sure, 0)) {  // near2_exact: the reference's own test, 2a*t in place of the estimate
+        float t = 0.0f;
+        const float ra = 0.25f * ra4;
+        const bool h = intersect_sphere(ro, rd, ra, g, t);
+        T = (2.0f * ra) * t;
+        ok = h & (t > 0.0f) & (T < rTlim_hi);
+      }
+      if (ok) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)i;
+        const unsigned long long old = __hip_atomic_fetch_min(P.key1 + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old != key) {  // (an equal key is the same sphere met in another cell: entered once)
+          const unsigned long long loser = old > key ? old : key;
+          __hip_atomic_fetch_min(P.t2 + owner, (uint32_t)(loser >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    if (last) break;
+    // requested here, used by the next round's stop rule: the LDS latency hides behind the loop's own bookkeeping
+    T1 = __uint_as_float((uint32_t)(__hip_atomic_load(P.key1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
+  }
+  PT_HIST_END(true);
+  const unsigned long long k = __hip_atomic_load(P.key1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  walk.s.T1 = __uint_as_float((uint32_t)(k >> 32));
+  walk.s.i1 = walk.s.T1 < INF ? (int)(uint32_t)k : 0;
+  walk.s.T2 = __uint_as_float(__hip_atomic_load(P.t2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  walk.tmax0 = tmax0, walk.tmax1 = tmax1, walk.tmax2 = tmax2;
+  walk.cidx = cidx;
+  walk.left = left, walk.k0 = k0, walk.k1 = k1;
+  walk.walking = walking;
+}
+
+__device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
+                                                            float& t_hit, int& idx) {
+  GridWalk w;
+  grid_begin(w, G, o, d, a);
+  grid_trips_pooled(w, G, pool_of_wave(sc.pool), o, d);
+  return grid_end(w, sc, G, n, o, d, t_hit, idx);
+}
+
+// variant 13's nearest-hit search
+__device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+  if (n <= 0) return false;
+  const float a = dot(d, d);
+  const GridLds& G = *sc.grid;
+  if (G.valid) {
+    const bool admitted = grid_admits(G, o, d, a);
+    PT_STATW(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);
+    if (admitted) return intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx);
   }
   return intersect_scene_screened_large(sc, n, o, d, make_ray_const(d), t_hit, idx);
 }

@@ -69,6 +69,11 @@
 #ifndef PT_GRID12_MIN_WAVES
 #define PT_GRID12_MIN_WAVES 4
 #endif
+#ifndef PT_POOL_MIN_WAVES
+// variant 13 (variant 11 with the sphere tests pooled across the wave, pt_grid.h) is issue-bound, not latency-bound like its
+// predecessor: four waves per SIMD with 128 registers and no spills beat six with 80 and 128 B of scratch (13.9 -> 13.3 ms)
+#define PT_POOL_MIN_WAVES 4
+#endif
 #define PT_GRID_MAX_SPHERES 2048
 #define PT_GRID_MIN_SPHERES 160
 
@@ -105,7 +110,10 @@ struct PixelKernelArgs {
 // one), 4 x {mean, M2}, and the 6 generator words (xorwow only; philox needs none)
 #define PT_CHUNK_WORDS 26
 #ifndef PT_CHUNKS
-#define PT_CHUNKS 8
+// chunks per pixel block of the automatic policy.  Measured at the headline frame (tools/chunk_sweep.py, profiles/r03):
+// 1 (off) 50.88 ms, 2: 50.14, 4: 50.22, 8: 50.07, 16: 50.23 -- two chunks take nearly all of the gain for one hand-over per
+// pixel (218 MB of HBM traffic per frame instead of the 1.5 GB seven hand-overs cost)
+#define PT_CHUNKS 2
 #endif
 #define PT_CHUNKS_MAX 16
 // A chunk may only be as long as keeps the worst chained wait (all chunks of a block co-resident: chunk k waits k chunk

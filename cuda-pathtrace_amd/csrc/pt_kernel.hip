@@ -14,29 +14,33 @@ namespace pt {
 // pixel_kernel: src/pathtrace.cu:203-257
 // LEAN selects the geometry-only LDS layout of many-sphere scenes (pt_scene_lds.h) at compile time, so the
 // 9-sphere kernels carry no trace of it.
-// REF builds the kernel for the reference's own configuration -- 9 spheres (Scene.h:23), MAX_BOUNCES 5 (pathtrace.cu:7) -- as
-// compile-time constants: no generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
+// REFB != 0 builds the kernel for the reference's own scene size -- 9 spheres (Scene.h:23) -- and a fixed bounce cap as
+// compile-time constants: REFB = 5 is the reference's MAX_BOUNCES (pathtrace.cu:7), REFB = 8 the interactive configuration
+// (BASELINE.json configs[4]).  No generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
 template <int VAR>
-constexpr int kBlockThreads = (VAR == 11 || VAR == 12) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
+constexpr int kBlockThreads = (VAR == 11 || VAR == 12 || VAR == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
 template <int VAR>
-constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
+constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POOL_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
 
-template <int RNG, int VAR, bool LEAN = false, bool REF = false>
+template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
 __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+  constexpr bool REF = REFB != 0;
   if constexpr (REF) {
     a.n_spheres = 9;
-    a.max_bounces = 5;
+    a.max_bounces = REFB;
   }
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
   // variants with a lean build run their LDS build only on scenes up to PT_SCREEN_MAX_SPHERES (launcher): the
   // many-sphere path is not even compiled into it, which keeps the hot loop's code small
   sc.small_only = !LEAN && (VAR == 6 || VAR == 8 || VAR == 10);
-  constexpr bool kRegen = (VAR == 10 || VAR == 11);
+  constexpr bool kRegen = (VAR == 10 || VAR == 11 || VAR == 13);
   GridLds grid;
-  if constexpr (VAR == 11 || VAR == 12) {  // the frame's grid, built by build_grid_kernel just before this launch
+  if constexpr (VAR == 11 || VAR == 12 || VAR == 13) {  // the frame's grid, built by build_grid_kernel just before this launch
     grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene + a.scene_lds_f4);  // after the two small tables
     sc.grid = &grid;
+    if constexpr (VAR == 13)  // the test pool of each wave follows the grid image (16-byte aligned)
+      sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres) + 15) & ~(size_t)15);
   }
 
   // Sample chunking (REF builds of variant 6): workgroup blockIdx.x = chunk * n_blocks + block renders samples
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       }
       bool escaped = false;
       if (n < a.max_bounces) {
-        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
+        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
         n++;
       }
       if (escaped | (n >= a.max_bounces)) {
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
       rng.begin_sample((uint32_t)i);
       F3 dir;
       primary_ray(rng, dir);
-      trace_ray<RNG, (VAR >= 7 ? 6 : VAR)>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
+      trace_ray<RNG, (VAR >= 7 ? 6 : VAR), REFB>(L, sc, a.n_spheres, eye, dir, rng, var, a.max_bounces);  // :231
     }
     if (by_progress) __builtin_amdgcn_s_setprio(0);
   }
@@ -378,7 +382,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
   } else {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
-                         VAR != 11 && VAR != 12;  // variants 11, 12: the LDS holds the grid until the last wave is done: plain stores there
+                         VAR != 11 && VAR != 12 && VAR != 13;  // variants 11-13: the LDS holds the grid until the last wave is done: plain stores there
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
 #pragma unroll
@@ -431,11 +435,12 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
 // skip-ahead, for tiles that are only moderately too small (about 4 one-lane waves per SIMD).
 constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
 
-template <int RNG, int kSplit, bool LEAN = false, bool REF = false>
+template <int RNG, int kSplit, bool LEAN = false, int REFB = 0>
 __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKernelArgs a) {
+  constexpr bool REF = REFB != 0;
   if constexpr (REF) {
     a.n_spheres = 9;
-    a.max_bounces = 5;
+    a.max_bounces = REFB;
   }
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
         sy /= (float)a.width;
       }
       F3 o1[1] = {eye}, d1[1] = {lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx)};
-      trace_paths<RNG, 1>(res, sc, a.n_spheres, o1, d1, g, a.max_bounces);
+      trace_paths<RNG, 1, REFB>(res, sc, a.n_spheres, o1, d1, g, a.max_bounces);
       rng = g[0];
     }
     // publish this lane's sample
@@ -668,7 +673,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 // LDS layout of a launch (pt_scene_lds.h): many-sphere scenes keep only the geometry in LDS
 // (variants 6, 8 and 10 -- the ones the automatic policy uses -- are also built for that layout)
 static inline bool lds_lean(int n, int variant) {
-  return variant == 11 || variant == 12 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
+  return variant == 11 || variant == 12 || variant == 13 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
 }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
@@ -679,6 +684,8 @@ static inline size_t scene_lds_f4(int n, int variant) {
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
   if (variant == 11 || variant == 12) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n) : 64;  // geometry + grid tables instead of the epilogue slice
+  if (variant == 13)  // + per wave the test ring and the owners' result slots
+    return (n <= pt::kGridMaxSpheres ? ((pt::grid_lds_bytes(n) + 15) & ~(size_t)15) : 64) + (PT_GRID_BLOCK_THREADS / 64) * pt::kPoolWaveBytes;
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
   return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
@@ -686,16 +693,22 @@ static inline size_t scene_lds_bytes(int n, int variant) { return scene_lds_f4(n
 
 typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
-static inline bool ref_config(int n, int max_bounces, int variant, bool planar) {
-  return n == 9 && max_bounces == 5 && !planar && (variant == 6 || variant == 8);
+// the bounce cap of the reference-configuration build these launch parameters run (5 or 8), 0 = a generic build
+static inline int ref_config(int n, int max_bounces, int variant, bool planar) {
+  return (n == 9 && (max_bounces == 5 || max_bounces == 8) && !planar && (variant == 6 || variant == 8)) ? max_bounces : 0;
 }
 
-static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool ref) {
+static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int ref) {
   const bool philox = rng_mode == PT_RNG_PHILOX;
-  if (ref && !lean) {
-    if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, true>;
+  if (ref == 5 && !lean) {
+    if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 5>;
     if (variant == 8)
-      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, true>;
+      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, 5> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, 5>;
+  }
+  if (ref == 8 && !lean) {
+    if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 8> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 8>;
+    if (variant == 8)
+      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, 8> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, 8>;
   }
   if (lean) {
     switch (variant) {
@@ -703,6 +716,7 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, bool 
       case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
       case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
       case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
+      case 13: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 13, true> : pt::pixel_kernel<PT_RNG_XORWOW, 13, true>;
 #if PT_BUILD_EXPERIMENTS
       case 12: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 12, true> : pt::pixel_kernel<PT_RNG_XORWOW, 12, true>;
 #endif
@@ -737,6 +751,12 @@ extern "C" int pt_debug_screen_stats(unsigned long long out[8], int reset) {
 #endif
 
 #ifdef PT_GRID_STATS
+extern "C" int pt_debug_grid_hist(unsigned long long out[256], int reset) {
+  static unsigned long long zero[256];
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_grid_hist), sizeof(zero)) != hipSuccess) return -2;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pt::g_grid_hist), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
 extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt::g_grid_stats), sizeof(zero)) != hipSuccess) return -2;
@@ -745,16 +765,16 @@ extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
 }
 #endif
 
-int pt_kernel_num_variants(void) { return 13; }
+int pt_kernel_num_variants(void) { return 14; }
 
-int pt_kernel_block_threads(int variant) { return (variant == 11 || variant == 12) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
+int pt_kernel_block_threads(int variant) { return (variant == 11 || variant == 12 || variant == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
 
 bool pt_kernel_has_variant(int variant) {
-  if (variant < 0 || variant >= 13) return false;
+  if (variant < 0 || variant >= 14) return false;
 #if PT_BUILD_EXPERIMENTS
   return true;
 #else
-  return variant == 0 || variant == 6 || variant == 8 || variant == 10 || variant == 11;
+  return variant == 0 || variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 13;
 #endif
 }
 
@@ -771,7 +791,7 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(
 int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
+  if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12 || variant == 13) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
   const size_t fixed = tail + pt::kTablesF4 * sizeof(float4);
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - fixed - 2 * sizeof(float4)) / (5 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
@@ -801,7 +821,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
     if (e != hipSuccess) return e;
   }
-  if (variant == 11 || variant == 12) {  // this frame's grid (the scene may have changed since the last one)
+  if (variant == 11 || variant == 12 || variant == 13) {  // this frame's grid (the scene may have changed since the last one)
     if (!a.accel) return hipErrorInvalidValue;
     hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, stream);
     if (e != hipSuccess) return e;

@@ -186,63 +186,127 @@ void worker_init(pt_mgpu* m, pt_mgpu::Rank& rk) {
   }
 }
 
+#if PT_BUILD_EXPERIMENTS
+// lab library: PT_LAB_MGPU_STALL="<rank>:<ms>" holds that rank's stream (a host function that sleeps) between its render and
+// its part of the exchange step, so the frame misses its deadline -- the only way to reach the PT_ETIMEOUT / ncclCommAbort
+// path on a machine where every peer is healthy (tests/test_mgpu_gpu.py)
+void lab_sleep_ms(void* ms) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms)); }
+#endif
+
+// One frame of one rank.  Errors before or inside the exchange step are REMEMBERED, not returned at once: a rank that failed
+// to render still posts its part of the grouped send/recv (the root would otherwise wait out the whole deadline for a tile
+// that never comes), and a group that was started is always ended.
 void worker_frame(pt_mgpu* m, pt_mgpu::Rank& rk) {
   const Job& j = m->job;
   const pt_mgpu::Rank& root = m->ranks[0];
   const size_t row_floats = (size_t)m->width * 14;
   const size_t count = (size_t)(rk.row_end - rk.row_begin) * row_floats;
   rk.kernel_ms = 0.0f;
+  int first_rc = PT_OK;  // the first failure of this frame; reported when the rank is done
+  auto note_hip = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    if (first_rc == PT_OK) {
+      snprintf(rk.err, sizeof(rk.err), "rank %d (device %d): %s: %s", rk.rank, rk.device, what, hipGetErrorString(e));
+      first_rc = e == hipErrorNoDevice ? PT_ENODEVICE : PT_EHIP;
+    }
+    return false;
+  };
+  auto note_pt = [&](int rc) {
+    if (rc == PT_OK) return true;
+    if (first_rc == PT_OK) {
+      snprintf(rk.err, sizeof(rk.err), "rank %d (device %d): %s", rk.rank, rk.device, pt_last_error());
+      first_rc = rc;
+    }
+    return false;
+  };
+  auto note_nccl = [&](ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return true;
+    if (first_rc == PT_OK) {
+      snprintf(rk.err, sizeof(rk.err), "rank %d (device %d): %s: %s", rk.rank, rk.device, what, m->rccl->GetErrorString(r));
+      first_rc = PT_ECOMM;
+    }
+    return false;
+  };
   // scene replica: the caller's spheres live on the root device (Scene::objects); 360 B .. 40 KB per frame
   const pt_sphere* scene = j.d_spheres;
+  bool scene_ok = true;
   if (rk.device != root.device && j.n_spheres > 0 && count) {
     if (rk.scene_capacity < j.n_spheres) {
-      if (rk.d_scene) W_HIP(hipFree(rk.d_scene));
+      if (rk.d_scene) (void)hipFree(rk.d_scene);
       rk.d_scene = nullptr;
-      W_HIP(hipMalloc((void**)&rk.d_scene, (size_t)j.n_spheres * sizeof(pt_sphere)));
-      rk.scene_capacity = j.n_spheres;
+      rk.scene_capacity = 0;
+      scene_ok = note_hip(hipMalloc((void**)&rk.d_scene, (size_t)j.n_spheres * sizeof(pt_sphere)), "hipMalloc(scene replica)");
+      if (scene_ok) rk.scene_capacity = j.n_spheres;
     }
-    W_HIP(hipMemcpyPeerAsync(rk.d_scene, rk.device, j.d_spheres, root.device, (size_t)j.n_spheres * sizeof(pt_sphere), rk.stream));
+    if (scene_ok)
+      scene_ok = note_hip(hipMemcpyPeerAsync(rk.d_scene, rk.device, j.d_spheres, root.device, (size_t)j.n_spheres * sizeof(pt_sphere), rk.stream),
+                          "hipMemcpyPeerAsync(scene replica)");
     scene = rk.d_scene;
   }
   float* target = in_place(m, rk) ? j.d_out + (size_t)rk.row_begin * row_floats : rk.d_tile;
-  if (count) {
-    W_HIP(hipEventRecord(rk.ev0, rk.stream));
-    W_PT(pt_renderer_enqueue(rk.renderer, target, scene, j.n_spheres, j.basis, j.eye, rk.stream));
-    W_HIP(hipEventRecord(rk.ev1, rk.stream));
+  bool timed = false;
+  if (count && scene_ok) {
+    timed = note_hip(hipEventRecord(rk.ev0, rk.stream), "hipEventRecord");
+    note_pt(pt_renderer_enqueue(rk.renderer, target, scene, j.n_spheres, j.basis, j.eye, rk.stream));
+    timed = note_hip(hipEventRecord(rk.ev1, rk.stream), "hipEventRecord") && timed;
   }
-  // ---- the exchange step ------------------------------------------------------------------------
+#if PT_BUILD_EXPERIMENTS
+  if (const char* st = getenv("PT_LAB_MGPU_STALL")) {
+    int r = -1, ms = 0;
+    if (sscanf(st, "%d:%d", &r, &ms) == 2 && r == rk.rank && ms > 0)
+      note_hip(hipLaunchHostFunc(rk.stream, lab_sleep_ms, (void*)(intptr_t)ms), "hipLaunchHostFunc");
+  }
+#endif
+  // ---- the exchange step: posted even by a rank whose render failed (the frame fails, but nobody waits for it) ----------
+  bool comm_broken = false;
   if (m->use_rccl) {
-    W_NCCL(m->rccl->GroupStart());
-    if (rk.rank == 0) {
-      for (const pt_mgpu::Rank& p : m->ranks) {
-        const size_t pc = (size_t)(p.row_end - p.row_begin) * row_floats;
-        if (pc && !in_place(m, p)) W_NCCL(m->rccl->Recv(j.d_out + (size_t)p.row_begin * row_floats, pc, ncclFloat, p.rank, rk.comm, rk.stream));
+    if (!rk.comm) {
+      comm_broken = true;
+    } else if (note_nccl(m->rccl->GroupStart(), "ncclGroupStart")) {
+      if (rk.rank == 0) {
+        for (const pt_mgpu::Rank& p : m->ranks) {
+          const size_t pc = (size_t)(p.row_end - p.row_begin) * row_floats;
+          if (pc && !in_place(m, p))
+            comm_broken |= !note_nccl(m->rccl->Recv(j.d_out + (size_t)p.row_begin * row_floats, pc, ncclFloat, p.rank, rk.comm, rk.stream), "ncclRecv");
+        }
       }
+      if (count && !in_place(m, rk)) comm_broken |= !note_nccl(m->rccl->Send(rk.d_tile, count, ncclFloat, 0, rk.comm, rk.stream), "ncclSend");
+      comm_broken |= !note_nccl(m->rccl->GroupEnd(), "ncclGroupEnd");  // a started group is always ended
+    } else {
+      comm_broken = true;
     }
-    if (count && !in_place(m, rk)) W_NCCL(m->rccl->Send(rk.d_tile, count, ncclFloat, 0, rk.comm, rk.stream));
-    W_NCCL(m->rccl->GroupEnd());
+    if (comm_broken && rk.comm) {  // peers may be waiting for operations this rank could not post: unblock them
+      (void)m->rccl->CommAbort(rk.comm);
+      rk.comm = nullptr;
+    }
   } else if (count && !in_place(m, rk)) {
-    W_HIP(hipMemcpyPeerAsync(j.d_out + (size_t)rk.row_begin * row_floats, root.device, rk.d_tile, rk.device, count * sizeof(float), rk.stream));
+    note_hip(hipMemcpyPeerAsync(j.d_out + (size_t)rk.row_begin * row_floats, root.device, rk.d_tile, rk.device, count * sizeof(float), rk.stream),
+             "hipMemcpyPeerAsync(tile)");
   }
   // ---- completion, with a deadline: a peer that never arrives must not hang the caller ----------------
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->opts.timeout_ms);
   for (;;) {
     const hipError_t q = hipStreamQuery(rk.stream);
     if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) W_HIP(q);
+    if (q != hipErrorNotReady) {
+      note_hip(q, "hipStreamQuery");
+      break;
+    }
     if (m->opts.timeout_ms > 0 && std::chrono::steady_clock::now() > deadline) {
       if (m->use_rccl && rk.comm) {
         (void)m->rccl->CommAbort(rk.comm);  // unblocks the device-side wait of the grouped send/recv
         rk.comm = nullptr;
       }
-      snprintf(rk.err, sizeof(rk.err), "rank %d (device %d): frame not complete after %d ms (exchange aborted)", rk.rank, rk.device,
-               m->opts.timeout_ms);
-      rk.rc = PT_ETIMEOUT;
+      if (first_rc == PT_OK)
+        snprintf(rk.err, sizeof(rk.err), "rank %d (device %d): frame not complete after %d ms (exchange aborted)", rk.rank, rk.device,
+                 m->opts.timeout_ms);
+      rk.rc = PT_ETIMEOUT;  // outranks whatever else went wrong: the object is unusable from here on
       return;
     }
     std::this_thread::sleep_for(std::chrono::microseconds(20));  // a frame is >= milliseconds; do not burn a core per rank
   }
-  if (count) W_HIP(hipEventElapsedTime(&rk.kernel_ms, rk.ev0, rk.ev1));
+  if (timed && first_rc == PT_OK) note_hip(hipEventElapsedTime(&rk.kernel_ms, rk.ev0, rk.ev1), "hipEventElapsedTime");
+  rk.rc = first_rc;
 }
 
 void worker_main(pt_mgpu* m, int index) {
@@ -284,6 +348,9 @@ int run_all(pt_mgpu* m, const char* what) {
     m->cv_go.notify_all();
     m->cv_done.wait(lock, [&] { return m->pending == 0; });
   }
+  // a timeout outranks every other failure (it is the one that makes the object unusable), then the first failing rank
+  for (const pt_mgpu::Rank& rk : m->ranks)
+    if (rk.rc == PT_ETIMEOUT) return pt_fail(rk.rc, "%s: %s", what, rk.err);
   for (const pt_mgpu::Rank& rk : m->ranks)
     if (rk.rc != PT_OK) return pt_fail(rk.rc, "%s: %s", what, rk.err);
   return PT_OK;
@@ -407,7 +474,9 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
   if (!d_out) return pt_fail(PT_EINVAL, "pt_mgpu_render: d_out is NULL");
   if (n_spheres < 0 || (n_spheres > 0 && !d_spheres)) return pt_fail(PT_EINVAL, "pt_mgpu_render: bad scene (%d spheres)", n_spheres);
   if (!basis || !eye) return pt_fail(PT_EINVAL, "pt_mgpu_render: basis/eye is NULL");
-  if (m->failed) return pt_fail(PT_ECOMM, "pt_mgpu_render: an earlier frame timed out and its exchange was aborted; destroy and re-create");
+  if (m->failed)
+    return pt_fail(PT_ECOMM, "pt_mgpu_render: an earlier frame timed out or lost its communicator (exchange aborted); the only call this "
+                             "object still accepts is pt_mgpu_destroy -- destroy and re-create");
   m->job.d_out = d_out;
   m->job.d_spheres = d_spheres;
   m->job.n_spheres = n_spheres;
@@ -415,7 +484,9 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
   memcpy(m->job.eye, eye, sizeof(m->job.eye));
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = run_all(m, "pt_mgpu_render");
-  if (rc == PT_ETIMEOUT) m->failed = true;
+  // unusable from here on if ANY rank timed out or has aborted its communicator, whichever rank's error is reported
+  for (const pt_mgpu::Rank& rk : m->ranks)
+    if (rk.rc == PT_ETIMEOUT || (m->use_rccl && !rk.comm)) m->failed = true;
   if (ms_out) *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }

@@ -39,7 +39,8 @@ struct SceneLds {
   const pt_sphere* global;  // the caller's array (lean build)
   bool lean;     // compile-time constant after inlining
   bool small_only;  // compile-time constant: this kernel build is only launched for scenes up to PT_SCREEN_MAX_SPHERES
-  const GridLds* grid;  // variant 11 only
+  const GridLds* grid;  // variants 11, 12, 13 only
+  void* pool;           // variant 13: the workgroup's pool area (pt_grid.h: per wave a test ring and the owners' result slots)
   uint32_t prim_mask;   // wave-uniform: the spheres the bounce-0 screen of this wave has to rank (pt_footprint.h); all ones = every sphere
 
   // geometry of sphere i, i wave-uniform
@@ -78,7 +79,7 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
   SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, tables ? reinterpret_cast<float*>(tab) : nullptr,
              tables ? reinterpret_cast<double*>(tab + kUnitTabSize / 4) : nullptr,
              tables ? reinterpret_cast<float*>(tab + kUnitTabSize / 4 + kUnitTabSize / 2) : nullptr, lds + 4 * n + kTablesF4,
-             spheres, lean, false, nullptr, 0xFFFFFFFFu};
+             spheres, lean, false, nullptr, nullptr, 0xFFFFFFFFu};
   const float qnan = __builtin_nanf("");
   if (tables) {
     for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x)  // the literal expression of helper_math's normalize (contract C2)

@@ -81,24 +81,30 @@ __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, 
   bool hit;
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
+  else if constexpr (VAR == 13)
+    hit = intersect_scene_v13(sc, nsph, o, d, t, idx);
   else
     hit = intersect_scene<VAR, PRIMARY, LAST>(sc, nsph, o, d, t, idx);
   return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
 }
 
 // trace_ray: src/pathtrace.cu:150-201
-template <int RNG, int VAR>
+// UNROLL_MB: a bounce count known at compile time (the kernel builds for one scene size and bounce cap, pt_kernel.hip: the
+// reference's MAX_BOUNCES 5, and the 8 of the interactive configuration) for which the path is emitted straight-line; the
+// generic builds (0) unroll the reference's five only.
+template <int RNG, int VAR, int UNROLL_MB = 0>
 __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, int nsph, F3 o, F3 d, Rng<RNG>& rng,
                                           Welford (&var)[4], int max_bounces) {
   F3 color = mk3(0.0f, 0.0f, 0.0f);
   F3 mask = mk3(1.0f, 1.0f, 1.0f);
 #if PT_UNROLL_BOUNCES
-  if (VAR >= 6 && max_bounces == 5) {  // the reference's MAX_BOUNCES (:7): straight-line, no loop state, n folds to constants
+  constexpr int kMB = UNROLL_MB >= 2 ? UNROLL_MB : 5;
+  if (VAR >= 6 && max_bounces == kMB) {  // straight-line, no loop state, n folds to constants
     if (!bounce_once<RNG, VAR, true>(L, sc, nsph, o, d, color, mask, rng, var, 0)) return;  // trace_ray starts at the eye
 #pragma unroll
-    for (int n = 1; n < 4; n++)
+    for (int n = 1; n < kMB - 1; n++)
       if (!bounce_once<RNG, VAR>(L, sc, nsph, o, d, color, mask, rng, var, n)) return;
-    if (!bounce_once<RNG, VAR, false, true>(L, sc, nsph, o, d, color, mask, rng, var, 4)) return;  // the last: colour only
+    if (!bounce_once<RNG, VAR, false, true>(L, sc, nsph, o, d, color, mask, rng, var, kMB - 1)) return;  // the last: colour only
   } else
 #endif
   {
@@ -128,7 +134,7 @@ struct PathResult {
 
 // trace_ray (src/pathtrace.cu:150-201) for P paths in lockstep; results are returned, not accumulated
 // primary_at_zero: the paths start at the eye the scene image was staged for (true for every caller in pt_kernel.hip)
-template <int RNG, int P>
+template <int RNG, int P, int UNROLL_MB = 0>  // UNROLL_MB: see trace_ray
 __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds& sc, int nsph, F3 (&o)[P], F3 (&d)[P],
                                             Rng<RNG> (&rng)[P], int max_bounces, bool primary_at_zero = true) {
   F3 color[P], mask[P];
@@ -206,10 +212,11 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     return true;
   };
 #if PT_UNROLL_BOUNCES
-  if (P == 1 && max_bounces == 5) {
+  constexpr int kMB = UNROLL_MB >= 2 ? UNROLL_MB : 5;
+  if (P == 1 && max_bounces == kMB) {
 #pragma unroll
-    for (int n = 0; n < 5; n++)
-      if (!bounce(n, n == 4)) break;
+    for (int n = 0; n < kMB; n++)
+      if (!bounce(n, n == kMB - 1)) break;
   } else
 #endif
   {

@@ -206,6 +206,10 @@ int pt_mgpu_create(int n_gpus, const int* devices, int width, int height, int sa
                    int threads_per_block, const pt_renderer_opts* opts, const pt_mgpu_opts* mopts,
                    pt_mgpu** out);
 int pt_mgpu_destroy(pt_mgpu* m);
+/* Error behaviour of pt_mgpu_render: a rank that cannot render still posts its part of the exchange (nobody waits for
+ * a tile that never comes) and the call reports the first failure.  After PT_ETIMEOUT, or any failure in which a rank lost
+ * its communicator (ncclCommAbort), the object is dead: every later pt_mgpu_render returns PT_ECOMM and pt_mgpu_destroy is
+ * the only call it still accepts.  Other failures (PT_EINVAL, PT_ELIMIT, PT_EHIP from a rank's render) leave it usable. */
 /* Renderer::Render (Renderer.h:55-76) for the whole frame: d_out ([height][width][14]) and
  * d_spheres live on devices[0] and must be complete (the call does not order itself after the
  * caller's streams); the scene is replicated to the other devices by peer copies (360 B .. 40 KB).

@@ -56,3 +56,32 @@ def test_bench_config3_line(gpu):
     j = _run([sys.executable, "bench.py", "--config", "cfg3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt-rng"])
     assert "4096x4096" in j["metric"] and "configs[2]" in j["config"]["workload"] and j["n_gpus"] == 1
     assert 40 < j["ms_per_step"] < 200 and j["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_other_configuration_lines(gpu):
+    """--config cfg4 / cfg4open / cfg5 (BASELINE.json configs[3], configs[4]) print the same line format and name their workload."""
+    for key, needle in (("cfg4", "configs[3], closed"), ("cfg4open", "configs[3], open"), ("cfg5", "configs[4]")):
+        j = _run([sys.executable, "bench.py", "--config", key, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+        assert needle in j["config"]["workload"] and j["n_gpus"] == 1 and j["value"] > 0
+        assert j["roofline"]["kernel_ms"] > 0 and j["roofline"]["traffic"] is None  # no stale counters on a config without a profile
+        assert (j["counter_based_rng"] is None) == (key != "cfg5") and (j["fast_mode"] is None) == (key != "cfg5")
+    assert "8 bounces" in j["metric"] and "512x512" in j["metric"]
+
+
+def test_bench_rank_failure_kills_the_job(gpu, tmp_path):
+    """`python bench.py --gpus 3` with one rank dying before the first frame: the launcher exits non-zero promptly and leaves
+    no rank behind (the survivors would otherwise wait in the gather forever)."""
+    import time
+    env = dict(os.environ, PT_BENCH_SHARED_GPU="1", PT_BENCH_BACKEND="gloo", PT_BENCH_TEST_DIE_RANK="1", PT_BENCH_TEST_PIDDIR=str(tmp_path))
+    t0 = time.perf_counter()
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "2", "--warmup", "1", "--spp", "8", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 17, (res.returncode, res.stderr[-1500:])
+    assert time.perf_counter() - t0 < 240
+    assert not [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]  # no bench line from a broken job
+    pids = [int(f.name) for f in tmp_path.iterdir()]
+    assert len(pids) == 3
+    time.sleep(0.5)
+    for pid in pids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)

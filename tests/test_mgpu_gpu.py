@@ -127,3 +127,70 @@ def test_cli_gpus_flag_forced_exchange(pt, oracle, gpu, tmp_path):
         assert np.array_equal(planes[names.index(nm)].view(np.uint32), ref[..., ch].view(np.uint32)), nm
     bad = subprocess.run([exe, "--size", "16", "-s", "1", "--gpus", "64", "-o", out], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "GPUassert:" in bad.stderr
+
+
+# ---- failure paths (lab library: PT_LAB_MGPU_STALL holds one rank's stream past the frame's deadline) --------------------
+def _stalled(lab, devices, monkeypatch, rank, **kw):
+    monkeypatch.setenv("PT_LAB_MGPU_STALL", f"{rank}:1500")
+    size = 48
+    m = lab.MultiRenderer(devices, size, size, 2, timeout_ms=200, **kw)
+    d_scene, n = lab.upload_scene(lab.scene_cornell())
+    d_out = lab.DeviceBuffer(size * size * 56)
+    return m, d_scene, n, d_out, lab.camera_basis(width=size, height=size)
+
+
+def test_timeout_peer_copy_ranks_then_object_is_dead(lab, gpu, monkeypatch):
+    """A rank whose stream does not drain before the deadline: PT_ETIMEOUT (not a hang, not PT_OK), every later render is
+    refused with PT_ECOMM, and destroy returns.  3 ranks sharing device 0, peer-copy exchange; rank 1 stalls for 1.5 s
+    against a 200 ms deadline."""
+    import time
+    m, d_scene, n, d_out, basis = _stalled(lab, [0, 0, 0], monkeypatch, 1, force_exchange=True)
+    t0 = time.perf_counter()
+    with pytest.raises(lab.PtError) as e:
+        m.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == -7 and "rank 1" in str(e.value) and time.perf_counter() - t0 < 1.4  # returned at the deadline, not after the stall
+    monkeypatch.delenv("PT_LAB_MGPU_STALL")
+    with pytest.raises(lab.PtError) as e:
+        m.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == -6 and "destroy" in str(e.value)
+    m.destroy()  # joins the workers; the stalled stream drains on its own
+    lab.check(lab.lib.pt_device_synchronize())
+    # a fresh object on the same device works
+    m2 = lab.MultiRenderer([0, 0, 0], 48, 48, 2, force_exchange=True)
+    assert m2.render(d_out.ptr, d_scene.ptr, n, basis) > 0
+    m2.destroy()
+
+
+def test_timeout_rccl_communicator_is_aborted(lab, gpu, monkeypatch):
+    """The same with the RCCL exchange (one-rank communicator, forced self send/recv): the deadline passes while the grouped
+    send/recv is still queued behind the stalled stream, the rank aborts its communicator (ncclCommAbort) and reports
+    PT_ETIMEOUT; the object refuses further frames and can be destroyed."""
+    m, d_scene, n, d_out, basis = _stalled(lab, [0], monkeypatch, 0, force_exchange=True, gather=lab.GATHER_RCCL)
+    assert m.backend().startswith("rccl")
+    with pytest.raises(lab.PtError) as e:
+        m.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == -7 and "aborted" in str(e.value)
+    monkeypatch.delenv("PT_LAB_MGPU_STALL")
+    with pytest.raises(lab.PtError) as e:
+        m.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert e.value.code == -6
+    m.destroy()
+    lab.check(lab.lib.pt_device_synchronize())
+
+
+def test_render_failure_of_one_rank_does_not_stall_the_others(pt, gpu):
+    """A rank that cannot render (here: every rank, a scene beyond the variant's staging limit is not reachable in the product
+    library, so a NULL scene with a positive count) fails the call at once with that rank's error -- not after the deadline --
+    and the object stays usable."""
+    import time
+    size = 32
+    m = pt.MultiRenderer([0, 0], size, size, 2, force_exchange=True, timeout_ms=5000)
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(size * size * 56)
+    basis = pt.camera_basis(width=size, height=size)
+    t0 = time.perf_counter()
+    with pytest.raises(pt.PtError) as e:
+        m.render(d_out.ptr, None, 9, basis)
+    assert e.value.code == -1 and time.perf_counter() - t0 < 2.0
+    assert m.render(d_out.ptr, d_scene.ptr, n, basis) > 0  # argument errors leave the object usable
+    m.destroy()

@@ -55,10 +55,10 @@ def test_matches_committed_fixture(pt, gpu, name):
 
 # ---- every kernel variant computes the same bits ---------------------------------------------------
 def _all_variants(pt, lab):
-    """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 10, 11) from libptcore.so,
+    """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 10, 11, 13) from libptcore.so,
     the experimental ones (1-5, 7, 9, 12) from libptcore_lab.so."""
     prod = pt.variants()
-    assert prod == [0, 6, 8, 10, 11] and lab.variants() == list(range(13))
+    assert prod == [0, 6, 8, 10, 11, 13] and lab.variants() == list(range(14))
     return [(pt, v) for v in prod] + [(lab, v) for v in lab.variants() if v not in prod]
 
 
@@ -255,7 +255,7 @@ def test_ray_origins_on_sphere_surfaces(pt, lab, oracle, gpu):
         for yaw in (-90.0, 90.0, 0.0):
             basis = pt.camera_basis(e, yaw, 0.0, size, size)
             ref = oracle.render(size, size, 2, spheres=many, basis=basis, eye=e)
-            for v in (None, 10, 11):
+            for v in (None, 10, 11, 13):
                 img, _ = pt.render_frame(size, size, 2, spheres=many, basis=basis, eye=e, variant=v)
                 assert_bit_exact(img, ref, f"eye on a sphere of the 300-sphere scene, nudge {nudge} yaw {yaw} variant {v}")
 
@@ -267,7 +267,7 @@ def test_planar_layout_is_the_transposed_frame(pt, lab, oracle, gpu, rng):
     family (one lane per pixel, four lanes per pixel, regeneration, grid), full frame and a row tile."""
     size, spp = 72, 5
     basis = pt.camera_basis(width=size, height=size)
-    for scene, variants in ((pt.scene_cornell(), (0, 6, 8, 9, None)), (pt.scene_random(300, seed=4), (6, 8, 10, 11, None))):
+    for scene, variants in ((pt.scene_cornell(), (0, 6, 8, 9, None)), (pt.scene_random(300, seed=4), (6, 8, 10, 11, 13, None))):
         ref = oracle.render(size, size, spp, spheres=scene, basis=basis, rng_mode=rng)
         for v in variants:
             mod = lab if v == 9 else pt
@@ -297,7 +297,7 @@ def test_uniform_grid_variant(pt, lab, oracle, gpu, rng):
         for eye, yaw, pitch in cams:
             basis = pt.camera_basis(eye, yaw, pitch, size, size)
             ref = oracle.render(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng)
-            for v in (11, None):
+            for v in (11, 13, None):  # 13: the same walk with the sphere tests pooled across the wave's lanes
                 img, _ = pt.render_frame(size, size, 3, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=v)
                 assert_bit_exact(img, ref, f"grid {name} eye={eye} variant={v}")
             # the lab library's variant 12 (same walk, decoupled from the shading per lane; a measured negative result)
@@ -305,7 +305,7 @@ def test_uniform_grid_variant(pt, lab, oracle, gpu, rng):
             assert_bit_exact(img, ref, f"grid {name} eye={eye} variant=12 (lab)")
     assert lab.grid_header(scenes["walls"])["valid"] == 1 and lab.grid_header(wide)["valid"] == 0
     r = pt.Renderer(size, size, 3, rng_mode=rng)
-    assert r.kernel_info(400)["variant"] == 11
+    assert r.kernel_info(400)["variant"] in (11, 13)
     # the grid belongs to the frame, not to the renderer: move the spheres between two frames
     basis = pt.camera_basis(width=size, height=size)
     a, b = scenes["walls"], scenes["walls"].copy()

@@ -70,9 +70,10 @@ for name, scene in cases:
         mode = ci % 2
         a, ms10 = frame(scene, basis, eye, 10, mode)
         b, ms11 = frame(scene, basis, eye, 11, mode)
-        diff = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+        c, ms13 = frame(scene, basis, eye, 13, mode)
+        diff = int((a.view(np.uint32) != b.view(np.uint32)).sum()) + int((a.view(np.uint32) != c.view(np.uint32)).sum())
         h = pt.grid_header(scene)
-        rec = {"case": name, "camera": ci, "rng": mode, "floats_different": diff, "ms_v10": round(ms10, 2), "ms_v11": round(ms11, 2),
+        rec = {"case": name, "camera": ci, "rng": mode, "floats_different": diff, "ms_v10": round(ms10, 2), "ms_v11": round(ms11, 2), "ms_v13": round(ms13, 2),
                "grid": {"valid": h["valid"], "dims": h["dims"], "n_items": h["n_items"], "n_big": h["n_big"]}}
         out.append(rec)
         print(json.dumps(rec), flush=True)

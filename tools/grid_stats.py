@@ -17,6 +17,8 @@ for walls in (True, False):
     d_out = pt.DeviceBuffer(1024 * 1024 * 56)
     st = (ctypes.c_ulonglong * 8)()
     pt.lib.pt_debug_grid_stats(st, 1)
+    if hasattr(pt.lib, "pt_debug_grid_hist"):
+        pt.lib.pt_debug_grid_hist((ctypes.c_ulonglong * 256)(), 1)
     ms = r.render(d_out.ptr, d_scene.ptr, n, basis)
     pt.lib.pt_debug_grid_stats(st, 1)
     walks, trips, lanes_t, rounds, lanes_s, entered, amb = [st[i] for i in range(7)]
@@ -26,4 +28,18 @@ for walls in (True, False):
     if len(sys.argv) > 3 and "amb" in sys.argv[3]:
         print(f"   ambiguous lanes {st[6]} of {entered}: unsure {st[1]}, near tie {st[2]}, at the limit {st[3]}, exact step doubted {st[4]}, exact step rejects the estimate's hit {st[7]}")
     print("   raw", [st[i] for i in range(8)], "wave-bounces (closed) =", 1024 * 1024 * spp * 5 // 64)
+    if hasattr(pt.lib, "pt_debug_grid_hist"):
+        hh = (ctypes.c_ulonglong * 256)()
+        pt.lib.pt_debug_grid_hist(hh, 1)
+        for k, name in enumerate(("tests per ray", "steps per ray", "test trips per wave walk", "step rounds per wave walk")):
+            v = [hh[64 * k + i] for i in range(64)]
+            tot = max(sum(v), 1)
+            mean = sum(i * x for i, x in enumerate(v)) / tot
+            cum, q = 0, {}
+            for i, x in enumerate(v):
+                cum += x
+                for f in (0.5, 0.9, 0.99):
+                    if f not in q and cum >= f * tot:
+                        q[f] = i
+            print(f"   hist {name}: mean {mean:.2f} p50 {q.get(0.5)} p90 {q.get(0.9)} p99 {q.get(0.99)} | " + " ".join(str(x) for x in v))
     r.destroy()
