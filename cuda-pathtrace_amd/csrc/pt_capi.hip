@@ -43,6 +43,7 @@ struct pt_renderer {
   int launch_variant;      // what fill_args chose for the launch being prepared
   // automatic variant choice (opts.variant == PT_VARIANT_AUTO)
   bool auto_variant;
+  uint64_t resident_pixels; // one-lane-per-pixel lanes the device holds at four waves per SIMD
   bool small_tile;         // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD one-lane-per-pixel waves per SIMD
   bool philox_split;       // fewer than 12: where the four-lane kernel wins with the counter-based generator
   bool spec_ok;            // variant 8's speculation has not been failing on this scene
@@ -96,7 +97,9 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   // 1000-sphere scene: 35.5 -> 25.7 ms at 16 spp; closed scenes: equal to variant 6).
   // A small closed tile still gains from four lanes per pixel (1/8 tile, 1000 spheres + walls: 17.9 vs 23.3 ms);
   // the speculation feedback above sends an open scene back to variant 10.
-  if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 11;  // fewer tests: the uniform grid
+  // fewer tests: the uniform grid, its sphere tests pooled across the lanes of a wave (variant 13; 11 is the same walk with
+  // every lane testing its own spheres: 1000 spheres + walls 132 -> 100 ms, open 47 -> 40 ms, profiles/r03)
+  if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
   if (n_spheres > PT_SCREEN_MAX_SPHERES)
     return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
   // philox is counter-based: no skip-ahead, no speculation.  The four-lane kernel wins below twelve one-lane waves per
@@ -236,6 +239,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->ev_start = r->ev_stop = nullptr;
   r->auto_variant = (o.variant == PT_VARIANT_AUTO);
   r->small_tile = false;
+  r->resident_pixels = 0;
   r->philox_split = true;
   r->spec_ok = true;
   r->d_fail = nullptr;
@@ -260,6 +264,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     e = hipGetDeviceProperties(&prop, r->device);
     if (e == hipSuccess) {
       const uint64_t simds = (uint64_t)prop.multiProcessorCount * 4u;
+      r->resident_pixels = simds * 4u * 64u;
       r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD;
       r->philox_split = (uint64_t)r->tile_pixels < simds * 64u * 12u;
     }
@@ -406,6 +411,8 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->chunks = chunking ? r->chunks : 0u;
   a->chunk_state = chunking ? r->d_chunk : nullptr;
   a->chunk_flag = chunking ? r->d_chunk + (size_t)PT_CHUNK_WORDS * r->tile_pixels : nullptr;
+  // a frame that fits the chip in at most two rounds of workgroups is mostly tail: its waves set their priority by progress
+  a->prio = (r->spp >= 4 && (uint64_t)r->tile_pixels <= 2u * r->resident_pixels) ? 1u : 0u;
   a->err_word = r->d_err;
   a->chunk_wait_ticks = r->chunk_wait_ticks;
   a->debug = r->debug;

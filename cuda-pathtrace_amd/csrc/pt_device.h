@@ -89,6 +89,21 @@ __device__ __forceinline__ void xorwow_skip(Xorwow& s, int n) {
   s.v0 = v0; s.v1 = v1; s.v2 = v2; s.v3 = v3; s.v4 = v4;
 }
 
+// the same for a step count known at compile time, straight-line: no loop, no trip-count arithmetic; the rotation the last
+// N % 5 steps leave is resolved by the register allocator instead of by moves
+template <int N>
+__device__ __forceinline__ void xorwow_skip_n(Xorwow& s) {
+  s.d += 362437u * (uint32_t)N;
+  uint32_t v[5] = {s.v0, s.v1, s.v2, s.v3, s.v4};
+#pragma unroll
+  for (int k = 0; k < N; k++) {  // step k reads the oldest word v[k % 5] and the newest v[(k + 4) % 5], and replaces the oldest
+    const uint32_t a = v[k % 5], e = v[(k + 4) % 5];
+    const uint32_t t = a ^ (a >> 2);
+    v[k % 5] = (e ^ (e << 4)) ^ (t ^ (t << 1));
+  }
+  s.v0 = v[N % 5]; s.v1 = v[(N + 1) % 5]; s.v2 = v[(N + 2) % 5]; s.v3 = v[(N + 3) % 5]; s.v4 = v[(N + 4) % 5];
+}
+
 // curand_uniform: (0,1] -- _curand_uniform's x * 2^-32 + 2^-33 (contract C5).  The product with a power of two is exact, so
 // the one fma below rounds the same exact sum the multiply-then-add form rounds: identical for every x (and checked for all
 // 2^32 of them, tests/test_unary_exhaustive_gpu.py), one instruction less per draw.

@@ -772,6 +772,13 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 //  * the owner reads its best estimate back (one ds_read) when it evaluates the stop rule of its next step.  That value
 //    may be stale by the entries still in the ring: the rule then fires later, never earlier -- more cells, more tests, the
 //    same superset argument as the look-ahead step of variant 11 (exactness appendix A.6 (iii-b)).
+//  * WALKS can move too (PT_POOL_SPLITS > 0: lab library only, see there why).  The step loop runs as long as the wave's longest walk (26 rounds for a mean of 7 steps): once at most
+//    PT_POOL_SPLIT_BELOW lanes are still walking, every lane with nothing left to do takes over the FAR HALF of the remaining
+//    parameter range of a walking lane -- it fetches that lane's home ray with ds_bpermute, enters the grid at the midpoint
+//    (minus the slack) with the entry-cell code of grid_begin, and from then on pushes entries tagged with the ray's HOME
+//    lane and stops by the home lane's best estimate, which all walkers of a ray share through the slot.  The donor walks on
+//    to the midpoint (plus the slack).  The cells visited are a superset of the single walker's (the ranges overlap by twice
+//    the slack; each walker stops only by the shared rule or at its range's end), so the tested spheres are too.
 // Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
 // expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
 // (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
@@ -781,12 +788,26 @@ constexpr int kPoolRing = 256;  // ring entries per wave: a round adds at most 6
 #endif
 constexpr int kPoolPush = PT_POOL_PUSH;
 static_assert(64 * kPoolPush + 63 < kPoolRing + 1, "pool ring too small");
-constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4;  // ring, best keys, runner-up estimates
+constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4 + 64 * 4;  // ring, best keys, runner-up estimates, donor list
+#ifndef PT_POOL_SPLITS
+// at most this many hand-overs of walk ranges per walk (0: never).  A measured negative result, compiled into the lab
+// library only (csrc/Makefile): at 1000 spheres + walls it takes the step rounds of a walk from 25.7 to 16.0 (16.7 lanes are
+// handed a range per walk) and the frame from 12.48 to 12.61 ms at 32 spp (open: 5.01 -> 5.44) -- the entry-cell code the
+// takers run and the cells both halves visit cost what the shorter loop saves (profiles/r03/README.md)
+#define PT_POOL_SPLITS 0
+#endif
+#ifndef PT_POOL_SPLIT_BELOW
+#define PT_POOL_SPLIT_BELOW 36 // ... considered when at most this many lanes of the wave are still walking
+#endif
+#ifndef PT_POOL_SPLIT_CELLS
+#define PT_POOL_SPLIT_CELLS 4.0f  // ... for walks with more than about this many cells left
+#endif
 
 struct PoolLds {
   uint32_t* ring;            // [kPoolRing] (owner lane << 16) | sphere index
   unsigned long long* key1;  // [64] per owner lane: (bits of the smallest estimate << 32) | its sphere
   uint32_t* t2;              // [64] per owner lane: bits of the second smallest estimate
+  uint32_t* donors;          // [64] lanes that hand the far half of their walk to an idle lane, by rank
 };
 constexpr unsigned long long kPoolEmpty = 0x7F800000FFFFFFFFull;  // +inf, no sphere
 
@@ -796,6 +817,7 @@ __device__ __forceinline__ PoolLds pool_of_wave(void* workgroup_base) {
   p.key1 = reinterpret_cast<unsigned long long*>(b);
   p.ring = reinterpret_cast<uint32_t*>(b + 64 * 8);
   p.t2 = reinterpret_cast<uint32_t*>(b + 64 * 8 + kPoolRing * 4);
+  p.donors = reinterpret_cast<uint32_t*>(b + 64 * 8 + kPoolRing * 4 + 64 * 4);
   return p;
 }
 
@@ -814,15 +836,21 @@ __device__ __forceinline__ float bperm_f(int byte_addr, float v) {
 __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds& G, const PoolLds& P, F3 o, F3 d) {
   const float INF = __builtin_inff();
   const int lane = threadIdx.x & 63;
-  const float two_a = 2.0f * walk.a, a4 = 4.0f * walk.a;
-  const float Tlim_hi = 1000000.0f * two_a * 1.0000153f;
-  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
+  const float a4 = 4.0f * walk.a;  // of the lane's OWN ray: what the testers fetch
+  // the walk this lane is advancing: its own ray's at first, later possibly the far part of another lane's (see above)
+  float two_a = 2.0f * walk.a;
+  float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
+  float Tcap = 1000000.0f * two_a * 1.0000153f;  // the walk ends where 2a t passes this: the 1e6 limit, or the range handed to another lane
+  int home = lane;                                // the lane whose ray this is: tags the ring entries, owns the result slots
   float tmax0 = walk.tmax0, tmax1 = walk.tmax1, tmax2 = walk.tmax2;
-  const float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
+  float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
   int cidx = walk.cidx;
-  const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
+  int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
   uint32_t left = walk.left, k0 = walk.k0, k1 = walk.k1;
   bool walking = walk.walking;
+#if PT_POOL_SPLITS > 0
+  int splits = 0;  // wave-uniform
+#endif
   // lanes of this wave that are here (the others are on the brute-force path, or their pixel is finished): ranks, not lane
   // numbers, index the ring
   const uint64_t here = __builtin_amdgcn_ballot_w64(true);
@@ -838,6 +866,9 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   PT_HIST_DECL;
   for (;;) {
     // (1) one step for every lane whose list is used up
+    // (Measured and dropped: requesting the next cell's list a round ahead, as variant 11 does, so that the two LDS round
+    // trips of a round overlap -- the extra cell every lane then runs ahead costs more tests than the overlap saves:
+    // 12.5 -> 13.3 ms at 32 spp, open 4.9 -> 5.2.)
     const bool need = walking & (k0 >= k1);
     if (__builtin_amdgcn_ballot_w64(need) != 0) {
       PT_STATW(3, 1);
@@ -847,7 +878,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
         PT_HIST_LANE(hist_steps, 1);
         const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
         const float reach = (t_exit - slack_t) * two_a;
-        const bool stop = (T1 * 1.0000077f < reach) | (reach > Tlim_hi);
+        const bool stop = (T1 * 1.0000077f < reach) | (reach > Tcap);
         const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
         const bool a1 = !a0 & (tmax1 <= tmax2);
         tmax0 = a0 ? tmax0 + tdel0 : tmax0;
@@ -878,7 +909,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
       const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
       const uint32_t p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
       const uint32_t pos = tail + p0 + 2u * p1;
-      const uint32_t tag = (uint32_t)lane << 16;
+      const uint32_t tag = (uint32_t)home << 16;
 #pragma unroll
       for (int j = 0; j < kPoolPush; j++)
         if (c > (uint32_t)j) P.ring[(pos + (uint32_t)j) & (uint32_t)(kPoolRing - 1)] = tag | it[j];
@@ -938,18 +969,96 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
       }
     }
     if (last) break;
+#if PT_POOL_SPLITS > 0
+    // (4) hand walk ranges to idle lanes (see the head of this section)
+    if (splits < PT_POOL_SPLITS) {
+      const uint64_t wm = __builtin_amdgcn_ballot_w64(walking);
+      const int nw = __builtin_popcountll(wm);
+      if (nw != 0 && nw <= PT_POOL_SPLIT_BELOW && nw < (int)n_here) {
+        // what a walking lane has left: from the exit of the cell it stands in to where the shared stop rule, its range's end or
+        // the box would end it.  Only the BALANCE of the hand-over depends on these numbers, never the coverage: the taker walks
+        // from the midpoint until the stop rule, its inherited cap or the box ends it, the donor until the midpoint.
+        const float t_cur = fminf(fminf(tmax0, tmax1), tmax2);
+        const float l0 = (float)(left & 0x1FFu), l1 = (float)((left >> 10) & 0x1FFu), l2 = (float)((left >> 20) & 0x1FFu);
+        const float t_box = fminf(fminf(tdel0 < INF ? tmax0 + l0 * tdel0 : INF, tdel1 < INF ? tmax1 + l1 * tdel1 : INF),
+                                  tdel2 < INF ? tmax2 + l2 * tdel2 : INF);
+        const float inv_2a = __builtin_amdgcn_rcpf(two_a);
+        const float t_end = fminf(fminf(t_box, Tcap * inv_2a), T1 * inv_2a + slack_t);
+        const float tdel_min = fminf(fminf(tdel0, tdel1), tdel2);
+        const bool donor = walking & (t_end - t_cur > PT_POOL_SPLIT_CELLS * tdel_min) & (t_end < INF);
+        const bool idle = !walking & (k0 >= k1);
+        const uint64_t dm = __builtin_amdgcn_ballot_w64(donor), im = __builtin_amdgcn_ballot_w64(idle);
+        const int nd = __builtin_popcountll(dm), ni = __builtin_popcountll(im);
+        const int np = nd < ni ? nd : ni;
+        if (np > 0) {
+          splits++;
+          PT_POOL_STAT(7, np);  // (stats build: slot 7 then counts lanes handed a range, not brute-force waves)
+          const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+          const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+          const bool gives = donor & (rd < (uint32_t)np), takes = idle & (ri < (uint32_t)np);
+          const float t_mid = 0.5f * (t_cur + t_end);
+          if (gives) P.donors[rd] = (uint32_t)lane;
+          const int from = takes ? (int)P.donors[ri] : lane;  // (DS operations of one wave execute in order)
+          // the donor's walk parameters, then the ray of the donor's HOME lane (whose o, d registers are its own ray's, always)
+          const int fa = from << 2;
+          const int n_home = __builtin_amdgcn_ds_bpermute(fa, home);
+          const float n_mid = bperm_f(fa, t_mid), n_cap = bperm_f(fa, Tcap);
+          const int ha = n_home << 2;
+          const F3 ho = mk3(bperm_f(ha, o.x), bperm_f(ha, o.y), bperm_f(ha, o.z));
+          const F3 hd = mk3(bperm_f(ha, d.x), bperm_f(ha, d.y), bperm_f(ha, d.z));
+          if (gives) Tcap = fminf(Tcap, (t_mid + 2.0f * slack_t) * two_a);  // (after the taker has read the old cap)
+          if (takes) {
+            home = n_home;
+            const float ha_ = dot(hd, hd);
+            two_a = 2.0f * ha_;
+            slack_t = G.h.slack * __builtin_amdgcn_rsqf(ha_);
+            Tcap = n_cap;
+            const float t_start = fmaxf(n_mid - 2.0f * slack_t, 0.0f);
+            // the entry cell and the DDA state of grid_begin, at t_start
+            const float gmin[3] = {G.h.ox, G.h.oy, G.h.oz};
+            const int dims[3] = {(int)G.h.nx, (int)G.h.ny, (int)G.h.nz};
+            const float oo[3] = {ho.x, ho.y, ho.z}, dd[3] = {hd.x, hd.y, hd.z};
+            const float tiny = __builtin_amdgcn_sqrtf(ha_) * 9.094947e-13f;
+            const int stride[3] = {1, dims[0], dims[0] * dims[1]};
+            int ncidx = 0;
+            uint32_t nleft = 0x20080200u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const bool par = !(fabsf(dd[k]) > tiny);
+              const float inv = par ? 0.0f : __builtin_amdgcn_rcpf(dd[k]);
+              const float p = oo[k] + dd[k] * t_start;
+              int ci = (int)floorf((p - gmin[k]) * G.h.inv_cs);
+              ci = ci < 0 ? 0 : (ci >= dims[k] ? dims[k] - 1 : ci);
+              const bool fwd = dd[k] > 0.0f;
+              const float bnd = gmin[k] + (float)(ci + (fwd ? 1 : 0)) * G.h.cs;
+              const float tm = par ? INF : (bnd - oo[k]) * inv;
+              const float td = par ? INF : G.h.cs * fabsf(inv);
+              const int sk = fwd ? stride[k] : -stride[k];
+              if (k == 0) { tmax0 = tm; tdel0 = td; cs0 = sk; }
+              if (k == 1) { tmax1 = tm; tdel1 = td; cs1 = sk; }
+              if (k == 2) { tmax2 = tm; tdel2 = td; cs2 = sk; }
+              ncidx += ci * stride[k];
+              nleft |= (uint32_t)(fwd ? dims[k] - 1 - ci : ci) << (10 * k);
+            }
+            cidx = ncidx;
+            left = nleft;
+            k0 = G.cell_start[cidx];
+            k1 = G.cell_start[cidx + 1];
+            walking = true;
+          }
+        }
+      }
+    }
+#endif
     // requested here, used by the next round's stop rule: the LDS latency hides behind the loop's own bookkeeping
-    T1 = __uint_as_float((uint32_t)(__hip_atomic_load(P.key1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
+    T1 = __uint_as_float((uint32_t)(__hip_atomic_load(P.key1 + home, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
   }
   PT_HIST_END(true);
   const unsigned long long k = __hip_atomic_load(P.key1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   walk.s.T1 = __uint_as_float((uint32_t)(k >> 32));
   walk.s.i1 = walk.s.T1 < INF ? (int)(uint32_t)k : 0;
   walk.s.T2 = __uint_as_float(__hip_atomic_load(P.t2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-  walk.tmax0 = tmax0, walk.tmax1 = tmax1, walk.tmax2 = tmax2;
-  walk.cidx = cidx;
-  walk.left = left, walk.k0 = k0, walk.k1 = k1;
-  walk.walking = walking;
+  (void)cidx;  // (the walk state is not handed back: it may be another ray's by now, and grid_end needs only the result)
 }
 
 __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,

@@ -105,6 +105,7 @@ struct PixelKernelArgs {
   uint32_t* err_word;          // device error word of the renderer (PT_DEVERR_*), OR-ed into by a kernel that cannot go on correctly
   uint64_t chunk_wait_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) a chunk waits for its predecessor before it gives up
   uint32_t debug;              // lab library only (PT_DEBUG_*): deliberate faults for the failure-path tests
+  uint32_t prio;               // 1: one-lane-per-pixel waves set their issue priority by progress (filled in by the launcher)
 };
 // words handed from one chunk of a pixel block to the next: 10 sums, 2 counts (colour; the three first-hit accumulators share
 // one), 4 x {mean, M2}, and the 6 generator words (xorwow only; philox needs none)

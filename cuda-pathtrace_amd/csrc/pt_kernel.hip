@@ -313,13 +313,17 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
     // together, and the tail disappears (the same frame: 54 ms; the headline's four rounds: 52.4 -> 50.8 ms).  Scheduling
     // only: no value changes.  Not for short waves (the setting costs them 0.5 %; their kernels have many rounds anyway).
     const int span = i_end - i_begin;  // this workgroup's samples (all of them unless the frame is chunked)
-    const bool by_progress = span >= PT_PRIO_MIN_SPP;
+    // ... and not for frames of many rounds of short waves.  A frame that fits the chip in ONE round (the interactive shape:
+    // 512^2 x 4 spp = exactly four waves per SIMD) is all tail, however short its waves: there the priority follows the
+    // sample index itself (config 5: 0.1218 -> see profiles/r03).  The launcher decides (a.prio).
+    const bool by_progress = a.prio != 0u && span >= 4;
     const int q1 = i_begin + span / 4, q2 = i_begin + span / 2, q3 = i_end - span / 4;
+    const int stride_mask = span >= 64 ? 15 : 0;  // how often the band is looked at
     const int i_stop = active ? i_end : i;
     for (; i < i_stop; i++) {  // :219
       if (by_progress) {
         const int iu = __builtin_amdgcn_readfirstlane(i);  // the sample index is the same in every lane that is in this loop
-        if ((iu & 15) == 0) {
+        if ((iu & stride_mask) == 0) {
           if (iu < q1) __builtin_amdgcn_s_setprio(3);
           else if (iu < q2) __builtin_amdgcn_s_setprio(2);
           else if (iu < q3) __builtin_amdgcn_s_setprio(1);
@@ -559,12 +563,14 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     }
     // publish this lane's sample
     float* rec = xl + lane * kRecWords;
-    const float lumC = luminance(res[0].color), lumN = luminance(res[0].normal0), lumA = luminance(res[0].albedo0);
+    const float lumC = luminance(res[0].color), lumN = luminance(res[0].normal0);
+    const float lumA = sc.lean ? luminance(res[0].albedo0) : res[0].lum_albedo0;  // staged per sphere where the scene image is (pt_scene_lds.h)
+    const uint32_t own_fl = (mine ? 1u : 0u) | (res[0].hit0 ? 2u : 0u) | (res[0].escaped ? 4u : 0u);
     *reinterpret_cast<float4*>(rec + 0) = make_float4(res[0].color.x, res[0].color.y, res[0].color.z, lumC);
     *reinterpret_cast<float4*>(rec + 4) = make_float4(res[0].normal0.x, res[0].normal0.y, res[0].normal0.z, lumN);
     *reinterpret_cast<float4*>(rec + 8) = make_float4(res[0].albedo0.x, res[0].albedo0.y, res[0].albedo0.z, lumA);
     *reinterpret_cast<float4*>(rec + 12) = make_float4(res[0].t0, 0.0f, 0.0f, res[0].t0);
-    reinterpret_cast<uint32_t*>(rec)[16] = (mine ? 1u : 0u) | (res[0].hit0 ? 2u : 0u) | (res[0].escaped ? 4u : 0u);
+    reinterpret_cast<uint32_t*>(rec)[16] = own_fl;
     if constexpr (RNG == PT_RNG_XORWOW) {
       uint32_t* ru = reinterpret_cast<uint32_t*>(rec) + 17;
       ru[0] = rng.st.d; ru[1] = rng.st.v0; ru[2] = rng.st.v1; ru[3] = rng.st.v2; ru[4] = rng.st.v3; ru[5] = rng.st.v4;
@@ -573,6 +579,29 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     // apply the round's samples in order to this lane's feature
     bool failed = false;
     int consumed = 0;  // samples of this round that count (all of them unless a speculation failed)
+    // Every record of every pixel group of this wave a traced sample that hit something and stayed inside (wave-uniform; in a
+    // closed scene: always, except in a ragged last wave): every enable below is true, so the sums and the Welford updates
+    // run unconditionally -- no selects -- and the generator state is the last record's.  Same operations in the same order.
+    const bool all_hits = kSplit == 4 && __builtin_amdgcn_ballot_w64(own_fl != 3u) == 0;
+    if (all_hits) {
+#pragma unroll
+      for (int j = 0; j < kSplit; j++) {
+        const float* rj = xl + (gbase + j) * kRecWords;
+#pragma unroll
+        for (int q = 0; q < kOwn; q++) {
+          const float4 v = *reinterpret_cast<const float4*>(rj + 4 * (s * kOwn + q));
+          sum0[q] = sum0[q] + v.x;
+          sum1[q] = sum1[q] + v.y;
+          sum2[q] = sum2[q] + v.z;
+          if (sc.lean) welford_update(w[q], v.w); else welford_update(w[q], v.w, sc.rcpn);
+        }
+      }
+      if constexpr (RNG == PT_RNG_XORWOW) {
+        const uint32_t* ru = reinterpret_cast<const uint32_t*>(xl + (gbase + kSplit - 1) * kRecWords) + 17;
+        final_state = Xorwow{ru[0], ru[1], ru[2], ru[3], ru[4], ru[5]};
+      }
+      consumed = kSplit;
+    } else {
 #pragma unroll
     for (int j = 0; j < kSplit; j++) {
       const float* rj = xl + (gbase + j) * kRecWords;
@@ -604,6 +633,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
       }
       consumed += valid ? 1 : 0;
     }
+    }
     __builtin_amdgcn_wave_barrier();  // records are rewritten next round
     if (!seq) {
       if (failed) {
@@ -613,7 +643,11 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
         if constexpr (RNG == PT_RNG_XORWOW) rng.st = final_state;  // its true final state (only lane 0 traces from here on)
       } else {
         base += kSplit;
-        if constexpr (RNG == PT_RNG_XORWOW) xorwow_skip(rng.st, (kSplit - 1) * D);
+        if constexpr (RNG == PT_RNG_XORWOW) {
+          // (reference-configuration builds: the step count is a compile-time constant unless the frame has one sample per pixel)
+          if (REFB != 0 && a.spp != 1) xorwow_skip_n<(kSplit - 1) * (2 + 2 * (REFB != 0 ? REFB : 1))>(rng.st);
+          else xorwow_skip(rng.st, (kSplit - 1) * D);
+        }
       }
     } else {
       base += 1;
@@ -815,6 +849,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   if (!fn) return hipErrorInvalidValue;
   PixelKernelArgs b = a;
   b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, variant);
+  b.prio = (a.spp >= PT_PRIO_MIN_SPP || a.prio != 0u) ? 1u : 0u;  // long waves always; short ones when the caller says the frame is one round
   const size_t lds = scene_lds_bytes(a.n_spheres, variant);
   if (lds > PT_LDS_BUDGET_BYTES) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)

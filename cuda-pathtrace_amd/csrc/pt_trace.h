@@ -128,6 +128,7 @@ __device__ __forceinline__ void trace_ray(TraceOutput& L, const SceneLds& sc, in
 struct PathResult {
   F3 color, normal0, albedo0;
   float t0;
+  float lum_albedo0;  // luminance(albedo0) (:193), from the scene image where that is staged per sphere (same operands, same bits)
   bool hit0;     // the primary ray hit something: first-bounce features exist (:187-195)
   bool escaped;  // the path left the scene: no colour-variance update (:157-161)
 };
@@ -149,6 +150,7 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
     res[p].normal0 = mk3(0.0f, 0.0f, 0.0f);
     res[p].albedo0 = mk3(0.0f, 0.0f, 0.0f);
     res[p].t0 = 0.0f;
+    res[p].lum_albedo0 = 0.0f;
   }
   // last: the final iteration of a path of known length -- only colour comes out of it (bounce_once's LAST)
   auto bounce = [&](int n, bool last) -> bool {  // false = every path of this lane has left the scene
@@ -167,6 +169,7 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
       intersect_paths<P>(sc, nsph, o, d, hit, t, idx);
     // stage 1 (straight-line for all paths, so their chains interleave): materials, draws, fast geometry
     F3 centre[P], emis[P], scol[P];
+    float lum_col[P];
     float u_az[P], u_el[P];
     BounceGeom bg[P];
     bool bad[P];
@@ -178,7 +181,8 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
       const int ix = alive[p] ? idx[p] : 0;
       const float4 g = sc.geom_lane(ix);
       centre[p] = mk3(g.x, g.y, g.z);
-      fetch_material(sc, ix, emis[p], scol[p]);
+      lum_col[p] = 0.0f;
+      fetch_material(sc, ix, emis[p], scol[p], n == 0 ? &lum_col[p] : nullptr);
       u_az[p] = 0.5f;
       u_el[p] = 0.5f;
       if (alive[p]) rng[p].bounce(n, u_az[p], u_el[p]);  // a dead path draws nothing
@@ -205,6 +209,7 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
           res[p].hit0 = true;
           res[p].normal0 = bg[p].normal;
           res[p].albedo0 = scol[p];
+          res[p].lum_albedo0 = lum_col[p];
           res[p].t0 = t[p];
         }
       }
