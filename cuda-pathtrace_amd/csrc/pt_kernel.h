@@ -16,6 +16,9 @@
 #ifndef PT_PRIO_MIN_SPP_REGEN  // the path-regeneration kernels (many-sphere scenes: a sample is long)
 #define PT_PRIO_MIN_SPP_REGEN 32
 #endif
+#ifndef PT_FOOTPRINT_MIN_SPP
+#define PT_FOOTPRINT_MIN_SPP 8  // the pixel-footprint analysis (pt_footprint.h) is done once per pixel: worth it from this many samples
+#endif
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // requested unroll of the variant-2/4 screening loop (hipcc ignores it for runtime trip counts)
 #endif
@@ -43,6 +46,9 @@
 #endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4  // __launch_bounds__ 2nd argument: the register allocator must allow 4 waves per SIMD (<= 128 VGPRs)
+#endif
+#ifndef PT_REF_MIN_WAVES
+#define PT_REF_MIN_WAVES 5  // ... of the reference-configuration builds of variant 6 (<= 96 VGPRs)
 #endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the

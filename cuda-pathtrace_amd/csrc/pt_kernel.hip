@@ -22,8 +22,13 @@ constexpr int kBlockThreads = (VAR == 11 || VAR == 12 || VAR == 13) ? PT_GRID_BL
 template <int VAR>
 constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POOL_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
 
+// the reference-configuration builds of variant 6 fit 96 registers (8-32 bytes of spills, outside the hot loop): five waves per SIMD instead of four
+// (headline frame 50.12 -> 49.81 ms, three alternating runs each, profiles/r03/README.md); every other build keeps its cap
+template <int VAR, int REFB>
+constexpr int kMinWavesR = (VAR == 6 && REFB != 0) ? PT_REF_MIN_WAVES : kMinWaves<VAR>;
+
 template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
-__global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+__global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   constexpr bool REF = REFB != 0;
   if constexpr (REF) {
     a.n_spheres = 9;
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, kMinWaves<VAR>) PT_KERNEL_
   if constexpr (REF && VAR == 6) {
 #ifndef PT_NO_FOOTPRINT
     // once per pixel: the spheres this pixel's primary rays can return; the wave ranks the union at bounce 0
-    if (a.spp >= 8) {
+    if (a.spp >= PT_FOOTPRINT_MIN_SPP) {
       auto dir_at = [&](float sx, float sy) {
         if (pow2_image) {
           sx *= inv_h;
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
 
   if constexpr (REF && kSplit == 4) {
 #ifndef PT_NO_FOOTPRINT
-    if (a.spp >= 8) {  // once per pixel: the spheres its primary rays can return (pt_footprint.h); the wave ranks the union
+    if (a.spp >= PT_FOOTPRINT_MIN_SPP) {  // once per pixel: the spheres its primary rays can return (pt_footprint.h); the wave ranks the union
       auto dir_at = [&](float sx, float sy) {
         if (pow2_image) {
           sx *= inv_h;
