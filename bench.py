@@ -466,7 +466,7 @@ def main():
                 "note": "56 B/pixel/frame algorithmic; the kernel is VALU/latency bound (about 2.4 kFLOP per sample, "
                         "f32+f64), so the HBM fraction is <<1% by construction.  traffic = everything the counters saw: the "
                         "output, the persistent generator state (24 B in + 24 B out per pixel) and, on frames of few long "
-                        "workgroups, the sample-chunk hand-overs (112 B x 7 x 2 per pixel: scheduling traffic, DESIGN.md 4)",
+                        "workgroups, one sample-chunk hand-over (104 B written + read per pixel: scheduling traffic, DESIGN.md 3)",
             },
             "valu_roofline": valu,
             "profile_stale": stale,

@@ -22,10 +22,11 @@
 #ifndef PT_SCREEN_UNROLL
 #define PT_SCREEN_UNROLL 9  // requested unroll of the variant-2/4 screening loop (hipcc ignores it for runtime trip counts)
 #endif
-// Kernel variants (all bit-identical): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
+// Kernel variants (all bit-identical; DESIGN.md section 3 = which runs when, Appendix B.2 = how they came about): 0 literal, 1 lean FP64, 2 screened, 3 screened with packed
 // FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
 // lane, 8 four lanes per pixel, 9 two lanes per pixel, 10 per-lane path regeneration (open scenes), 11 = 10 + a
-// conservative uniform grid over the small spheres (pt_grid.h).
+// conservative uniform grid over the small spheres (pt_grid.h), 12 = 11 with walk and shading decoupled per lane (lab), 13 = 11 with
+// the sphere tests pooled across the lanes of a wave (pt_grid.h, "variant 13").
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES

@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB>)) P
 
 // ---- variant 8: four lanes per pixel (small tiles) ----------------------------------------------
 // A rank of an 8-GPU run renders 131 072 pixels = 2 waves per SIMD with one lane per pixel, which is
-// latency-bound (DESIGN.md 4).  Here lane (pixel, s) traces samples s, s+4, s+8, ... so the same tile
+// latency-bound (DESIGN.md Appendix B.2).  Here lane (pixel, s) traces samples s, s+4, s+8, ... so the same tile
 // has 4x the waves.  What the contract fixes -- one sequential generator per pixel, sequential float
 // sums, sequential Welford updates -- is preserved:
 //  * xorwow: lane s starts from the pixel's state advanced by s*D draws and skips 3*D draws after each
