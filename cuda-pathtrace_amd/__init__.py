@@ -156,7 +156,7 @@ if IS_LAB:
 
 
 def variants():
-    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 10, 11; lab: 0..12)."""
+    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 9, 10, 11, 13; lab: 0..13)."""
     out = []
     o = RendererOpts()
     for v in range(14):

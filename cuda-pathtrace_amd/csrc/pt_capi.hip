@@ -44,8 +44,9 @@ struct pt_renderer {
   // automatic variant choice (opts.variant == PT_VARIANT_AUTO)
   bool auto_variant;
   uint64_t resident_pixels; // one-lane-per-pixel lanes the device holds at four waves per SIMD
+  double waves_per_simd;    // one-lane-per-pixel waves of the tile per SIMD
   bool small_tile;         // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD one-lane-per-pixel waves per SIMD
-  bool philox_split;       // fewer than 12: where the four-lane kernel wins with the counter-based generator
+  bool philox_split;       // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX: where the four-lane kernel wins with the counter-based generator
   bool spec_ok;            // variant 8's speculation has not been failing on this scene
   uint32_t* d_fail;        // device counter written by variant 8
   uint32_t* h_fail;        // pinned host copy, valid once ev_fail has completed
@@ -81,9 +82,29 @@ static int mark_last(pt_renderer* r, hipStream_t stream) {
   return PT_OK;
 }
 
-// Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD (measured:
-// 4 waves/SIMD: 21.3 vs 22.3 ms, 2 waves/SIMD: 11.3 vs 12.7 ms, 8 and more: variant 6 wins).
-#define PT_SPLIT_MAX_WAVES_PER_SIMD 6
+// Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD.  Round 3 (tools/tile_policy.py,
+// profiles/r03/tile_policy.json; 1024 spp, xorwow): with five waves resident, progress priorities and sample chunking the
+// one-lane kernel takes about 3.35 ms per started wave-round, the four-lane kernel 3.65 ms per wave's worth of pixels --
+// 2 waves/SIMD (1/8 frame): 8.09 vs 7.48 ms, 2.5: 10.99 vs 9.12, 3: 10.09 vs 10.92, 3.5: 13.29 vs 12.88, 4 (1/4 frame): 13.41 vs
+// 14.53, 5: 16.46 vs 18.36 (rounds 1-2: 6).  philox (no skip-ahead): 4: 14.31 vs 13.45, 5: 16.88 vs 17.14, 8: 26.2 vs 26.9
+// (round 2: 12).
+// In the reference configuration (9 spheres, 5 or 8 bounces) there is a kernel in between: variant 9, TWO lanes per pixel, a
+// third of the skip-ahead, one round of four waves on a tile of two one-lane waves per SIMD (the 1/8 frame: 6.90 ms against
+// 7.55 and 8.14); by one-lane waves per SIMD w, kernel ms of variants 6 / 8 / 9: 1: 6.87 / 3.94 / 4.50, 1.5: 8.18 / 5.76 / 5.57,
+// 2: 8.14 / 7.55 / 6.90, 2.5: 11.08 / 9.14 / 9.53, 3: 10.17 / 10.98 / 10.59, 3.5: 13.33 / 12.91 / 11.99, 4: 13.37 / 14.53 / 14.19,
+// 5: 16.54 / 18.45 / 17.52.  The steps are wave counts: variant 6 takes ceil(w) wave times, variant 9 ceil(2w / 4) rounds.
+#define PT_SPLIT_MAX_WAVES_PER_SIMD 3
+#define PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX 5
+
+// the split kernel (8, 9) or 6 for a small xorwow tile of the reference configuration, by one-lane waves per SIMD
+static int small_tile_variant(double w) {
+  if (w <= 1.25) return 8;
+  if (w <= 2.0) return 9;
+  if (w < 2.75) return 8;
+  if (w <= 3.0) return PT_DEFAULT_VARIANT;
+  if (w <= 3.5) return 9;
+  return PT_DEFAULT_VARIANT;
+}
 
 static int effective_variant(pt_renderer* r, int n_spheres) {
   if (r->opts.fast_math) return PT_VARIANT_FAST;
@@ -102,12 +123,14 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
   if (n_spheres > PT_SCREEN_MAX_SPHERES)
     return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
-  // philox is counter-based: no skip-ahead, no speculation.  The four-lane kernel wins below twelve one-lane waves per
-  // SIMD (tools/philox_policy.py, 1024 spp: half frame 28.2 vs 28.7 ms, 1/8 frame 7.5 vs 8.7), the one-lane kernel above
-  // (full frame 53.9 vs 55.4 ms)
+  // philox is counter-based: no skip-ahead, no speculation.  The four-lane kernel wins below five one-lane waves per
+  // SIMD, the one-lane kernel above (numbers at PT_SPLIT_MAX_WAVES_PER_SIMD)
   if (r->opts.rng_mode == PT_RNG_PHILOX) return (r->spp >= 4 && r->philox_split) ? 8 : PT_DEFAULT_VARIANT;
   // xorwow: splitting must amortise the generator skip-ahead and only pays on small tiles
-  return (r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : PT_DEFAULT_VARIANT;
+  if (!(r->spec_ok && r->spp >= 8)) return PT_DEFAULT_VARIANT;
+  if (pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0)
+    return small_tile_variant(r->waves_per_simd);  // the reference configuration: every kernel has a build for it
+  return r->small_tile ? 8 : PT_DEFAULT_VARIANT;
 }
 
 extern "C" {
@@ -217,8 +240,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.chunks < 0 || o.chunks > PT_CHUNKS_MAX || o.reserved != 0)
     return pt_fail(PT_EINVAL, "pt_renderer_create: chunks %d (0 = automatic, 1 = off, 2..%d), reserved %d (must be 0)", o.chunks, PT_CHUNKS_MAX, o.reserved);
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
-    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 10, 11, 13; "
-                              "the experiments 1-5, 7, 9, 12 live in libptcore_lab.so)", o.variant);
+    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 9, 10, 11, 13; "
+                              "the experiments 1-5, 7, 12 live in libptcore_lab.so)", o.variant);
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
 
@@ -240,6 +263,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->auto_variant = (o.variant == PT_VARIANT_AUTO);
   r->small_tile = false;
   r->resident_pixels = 0;
+  r->waves_per_simd = 1e9;
   r->philox_split = true;
   r->spec_ok = true;
   r->d_fail = nullptr;
@@ -265,8 +289,9 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     if (e == hipSuccess) {
       const uint64_t simds = (uint64_t)prop.multiProcessorCount * 4u;
       r->resident_pixels = simds * 4u * 64u;
+      r->waves_per_simd = (double)r->tile_pixels / (double)(simds * 64u);
       r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD;
-      r->philox_split = (uint64_t)r->tile_pixels < simds * 64u * 12u;
+      r->philox_split = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX;
     }
   }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_fail, sizeof(uint32_t));
@@ -428,7 +453,7 @@ static hipError_t launch(pt_renderer* r, const PixelKernelArgs& a, hipStream_t s
 }
 
 static int watch_begin(pt_renderer* r, hipStream_t stream, bool* watching) {
-  *watching = r->auto_variant && r->launch_variant == 8 && !r->fail_pending;
+  *watching = r->auto_variant && (r->launch_variant == 8 || r->launch_variant == 9) && !r->fail_pending;
   if (*watching) PT_HIP(hipMemsetAsync(r->d_fail, 0, sizeof(uint32_t), stream));
   return PT_OK;
 }

@@ -137,6 +137,7 @@ struct PixelKernelArgs {
 #define PT_FAST_LDS_SPHERES 64  // the fast kernel stages scenes up to this size into LDS, larger ones are read in place
 int pt_kernel_num_variants(void);
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks);
+int pt_kernel_ref_bounces(int n_spheres, int max_bounces, int variant, bool planar);  // bounce cap of the reference-configuration build a launch runs, 0 = generic build
 int pt_kernel_block_threads(int variant);  // workgroup size the launcher uses
 bool pt_kernel_has_variant(int variant);  // compiled into this library?
 const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_bounces, bool planar);  // the function a launch with these parameters runs

@@ -440,8 +440,10 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB>)) P
 //    continues in sequential mode (lane 0 traces, all four still accumulate) from that sample's true
 //    final state.  Never happens in a closed scene; in an open one the kernel degrades to 1/4
 //    efficiency for that pixel but stays exact.
-// Variant 9 is the same kernel with TWO lanes per pixel, each owning two features: half the generator
-// skip-ahead, for tiles that are only moderately too small (about 4 one-lane waves per SIMD).
+// Variant 9 is the same kernel with TWO lanes per pixel, each owning two features: a third of the generator
+// skip-ahead (D instead of 3 D draws per sample), for tiles that are only moderately too small -- with its reference-
+// configuration build (round 3) the fastest kernel on a tile of two one-lane waves per SIMD, which it turns into ONE round of
+// four (the 1/8 frame of an 8-GPU run: 6.90 ms against variant 8's 7.55 and variant 6's 8.14; pt_capi.hip, small_tile_variant).
 constexpr int kRecWords = 24;  // 4 feature blocks {v0,v1,v2,x} + flags + 6 state words, padded
 
 template <int RNG, int kSplit, bool LEAN = false, int REFB = 0>
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
-  sc.small_only = !LEAN && kSplit == 4;  // variant 8 has a lean build for larger scenes, variant 9 has not
+  sc.small_only = !LEAN && (kSplit == 4 || REF);  // variant 8 has a lean build for larger scenes, variant 9 has not (its REF builds see 9 spheres)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
   const int gbase = lane & ~(kSplit - 1);
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
   const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
 
-  if constexpr (REF && kSplit == 4) {
+  if constexpr (REF) {
 #ifndef PT_NO_FOOTPRINT
     if (a.spp >= PT_FOOTPRINT_MIN_SPP) {  // once per pixel: the spheres its primary rays can return (pt_footprint.h); the wave ranks the union
       auto dir_at = [&](float sx, float sy) {
@@ -587,7 +589,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     // Every record of every pixel group of this wave a traced sample that hit something and stayed inside (wave-uniform; in a
     // closed scene: always, except in a ragged last wave): every enable below is true, so the sums and the Welford updates
     // run unconditionally -- no selects -- and the generator state is the last record's.  Same operations in the same order.
-    const bool all_hits = kSplit == 4 && __builtin_amdgcn_ballot_w64(own_fl != 3u) == 0;
+    const bool all_hits = __builtin_amdgcn_ballot_w64(own_fl != 3u) == 0;
     if (all_hits) {
 #pragma unroll
       for (int j = 0; j < kSplit; j++) {
@@ -734,8 +736,9 @@ typedef void (*pixel_kernel_fn)(PixelKernelArgs);
 
 // the bounce cap of the reference-configuration build these launch parameters run (5 or 8), 0 = a generic build
 static inline int ref_config(int n, int max_bounces, int variant, bool planar) {
-  return (n == 9 && (max_bounces == 5 || max_bounces == 8) && !planar && (variant == 6 || variant == 8)) ? max_bounces : 0;
+  return (n == 9 && (max_bounces == 5 || max_bounces == 8) && !planar && (variant == 6 || variant == 8 || variant == 9)) ? max_bounces : 0;
 }
+int pt_kernel_ref_bounces(int n_spheres, int max_bounces, int variant, bool planar) { return ref_config(n_spheres, max_bounces, variant, planar); }
 
 static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int ref) {
   const bool philox = rng_mode == PT_RNG_PHILOX;
@@ -743,11 +746,15 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int r
     if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 5>;
     if (variant == 8)
       return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, 5> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, 5>;
+    if (variant == 9)
+      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2, false, 5> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2, false, 5>;
   }
   if (ref == 8 && !lean) {
     if (variant == 6) return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 8> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 8>;
     if (variant == 8)
       return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, false, 8> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, false, 8>;
+    if (variant == 9)
+      return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2, false, 8> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2, false, 8>;
   }
   if (lean) {
     switch (variant) {
@@ -764,6 +771,7 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int r
   }
   switch (variant) {
     case 0: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 0> : pt::pixel_kernel<PT_RNG_XORWOW, 0>;
+    case 9: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2>;
 #if PT_BUILD_EXPERIMENTS  // measured negative results and stepping stones: libptcore_lab.so only
     case 1: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 1> : pt::pixel_kernel<PT_RNG_XORWOW, 1>;
     case 2: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 2> : pt::pixel_kernel<PT_RNG_XORWOW, 2>;
@@ -771,7 +779,6 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int r
     case 4: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 4> : pt::pixel_kernel<PT_RNG_XORWOW, 4>;
     case 5: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 5> : pt::pixel_kernel<PT_RNG_XORWOW, 5>;
     case 7: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 7> : pt::pixel_kernel<PT_RNG_XORWOW, 7>;
-    case 9: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 2> : pt::pixel_kernel_split<PT_RNG_XORWOW, 2>;
 #endif
     case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6> : pt::pixel_kernel<PT_RNG_XORWOW, 6>;
     case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4>;
@@ -813,7 +820,7 @@ bool pt_kernel_has_variant(int variant) {
 #if PT_BUILD_EXPERIMENTS
   return true;
 #else
-  return variant == 0 || variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 13;
+  return variant == 0 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 11 || variant == 13;
 #endif
 }
 

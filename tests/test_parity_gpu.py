@@ -55,10 +55,10 @@ def test_matches_committed_fixture(pt, gpu, name):
 
 # ---- every kernel variant computes the same bits ---------------------------------------------------
 def _all_variants(pt, lab):
-    """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 10, 11, 13) from libptcore.so,
-    the experimental ones (1-5, 7, 9, 12) from libptcore_lab.so."""
+    """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 9, 10, 11, 13) from libptcore.so,
+    the experimental ones (1-5, 7, 12) from libptcore_lab.so."""
     prod = pt.variants()
-    assert prod == [0, 6, 8, 10, 11, 13] and lab.variants() == list(range(14))
+    assert prod == [0, 6, 8, 9, 10, 11, 13] and lab.variants() == list(range(14))
     return [(pt, v) for v in prod] + [(lab, v) for v in lab.variants() if v not in prod]
 
 
@@ -270,7 +270,7 @@ def test_planar_layout_is_the_transposed_frame(pt, lab, oracle, gpu, rng):
     for scene, variants in ((pt.scene_cornell(), (0, 6, 8, 9, None)), (pt.scene_random(300, seed=4), (6, 8, 10, 11, 13, None))):
         ref = oracle.render(size, size, spp, spheres=scene, basis=basis, rng_mode=rng)
         for v in variants:
-            mod = lab if v == 9 else pt
+            mod = pt
             img, _ = mod.render_frame(size, size, spp, spheres=scene, basis=basis, rng_mode=rng, variant=v, layout=pt.LAYOUT_PLANAR)
             planes = img.reshape(14, size, size)
             assert_bit_exact(np.ascontiguousarray(planes.transpose(1, 2, 0)), ref, f"planar variant={v}")
@@ -526,28 +526,43 @@ def test_automatic_variant_policy(pt, oracle, gpu):
     big = pt.Renderer(1024, 1024, 8)
     assert big.kernel_info(9)["variant"] == 6
     big.destroy()
-    # counter-based generator: four lanes per pixel pay below twelve one-lane waves per SIMD (half a 1024^2 frame), not above
+    # the crossover (tools/tile_policy.py): xorwow below three one-lane waves per SIMD (a quarter of a 1024^2 frame has four),
+    # the counter-based generator below five
+    quarter = pt.Renderer(1024, 1024, 1024, row_begin=0, row_end=256)
+    assert quarter.kernel_info(9)["variant"] == 6
+    quarter.destroy()
+    for rows, expect in ((64, 8), (128, 9), (160, 8), (192, 6), (224, 9)):  # 1, 2, 2.5, 3, 3.5 one-lane waves per SIMD
+        r = pt.Renderer(1024, 1024, 1024, row_begin=0, row_end=rows)
+        assert r.kernel_info(9)["variant"] == expect, rows
+        r.destroy()
+    r = pt.Renderer(1024, 1024, 1024, row_begin=0, row_end=128, max_bounces=6)  # no reference-configuration build: four lanes
+    assert r.kernel_info(9)["variant"] == 8
+    r.destroy()
     bigp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX)
     assert bigp.kernel_info(9)["variant"] == 6
     bigp.destroy()
     halfp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=512)
-    assert halfp.kernel_info(9)["variant"] == 8
+    assert halfp.kernel_info(9)["variant"] == 6
     halfp.destroy()
+    quarterp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=256)
+    assert quarterp.kernel_info(9)["variant"] == 8
+    quarterp.destroy()
     few = pt.Renderer(256, 256, 2)  # too few samples to split
     assert few.kernel_info(9)["variant"] == 6
     few.destroy()
 
 
+@pytest.mark.parametrize("variant", [8, 9], ids=["four_lanes", "two_lanes"])
 @pytest.mark.parametrize("scene", ["closed", "open"])
 @pytest.mark.parametrize("spp", [3, 8, 13])
-def test_four_lane_kernel_keeps_generator_state_across_frames(pt, oracle, gpu, scene, spp):
-    """Variant 8 forced: the generator state written back after a frame must be the sequential one
+def test_four_lane_kernel_keeps_generator_state_across_frames(pt, oracle, gpu, scene, spp, variant):
+    """Variants 8 and 9 forced: the generator state written back after a frame must be the sequential one
     (also when speculation failed and the pixel finished in sequential mode, and when spp is not a
-    multiple of four), so later frames continue the reference's stream."""
+    multiple of the lanes per pixel), so later frames continue the reference's stream."""
     size = 40
     sph = pt.scene_cornell() if scene == "closed" else pt.scene_cornell()[[1, 3, 6, 7, 8]]
     basis = pt.camera_basis(width=size, height=size)
-    r = pt.Renderer(size, size, spp, variant=8)
+    r = pt.Renderer(size, size, spp, variant=variant)
     d_scene, n = pt.upload_scene(sph)
     d_out = pt.DeviceBuffer(size * size * 14 * 4)
     st = oracle.setup_random(size, size)
