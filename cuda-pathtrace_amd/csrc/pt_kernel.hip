@@ -22,13 +22,15 @@ constexpr int kBlockThreads = (VAR == 11 || VAR == 12 || VAR == 13) ? PT_GRID_BL
 template <int VAR>
 constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POOL_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
 
-// the reference-configuration builds of variant 6 fit 96 registers (8-32 bytes of spills, outside the hot loop): five waves per SIMD instead of four
-// (headline frame 50.12 -> 49.81 ms, three alternating runs each, profiles/r03/README.md); every other build keeps its cap
-template <int VAR, int REFB>
-constexpr int kMinWavesR = (VAR == 6 && REFB != 0) ? PT_REF_MIN_WAVES : kMinWaves<VAR>;
+// the reference-configuration builds of variant 6 with the XORWOW generator fit 96 registers (12 bytes of spills, in cold code:
+// WRITE_SIZE stays at the algorithmic bytes): five waves per SIMD instead of four (headline frame 50.12 -> 49.81 ms, three
+// alternating runs each, profiles/r03/README.md).  Not the philox builds: their spills are warm (WRITE_SIZE 143 -> 400 MB per
+// frame) and buy nothing (51.1 vs 51.4 ms); every other build keeps its cap as well.
+template <int VAR, int REFB, int RNG>
+constexpr int kMinWavesR = (VAR == 6 && REFB != 0 && RNG == PT_RNG_XORWOW) ? PT_REF_MIN_WAVES : kMinWaves<VAR>;
 
 template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
-__global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+__global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   constexpr bool REF = REFB != 0;
   if constexpr (REF) {
     a.n_spheres = 9;
