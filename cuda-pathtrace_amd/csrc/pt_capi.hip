@@ -55,7 +55,8 @@ struct pt_renderer {
   uint32_t* d_accel;       // variant 11's grid tables (rebuilt on the device before every frame)
   uint32_t* d_chunk;       // sample chunking (pt_kernel.hip): PT_CHUNK_WORDS words per tile pixel + one flag per pixel block; allocated
                            // by the first launch that chunks (never for renderers whose kernels do not), or null
-  uint32_t chunks;         // how many chunks a frame of this renderer is split into when the kernel supports it (0 = off)
+  uint32_t chunks;         // how many chunks a frame of this renderer is split into when the kernel supports it (0 = off): variant 6 ...
+  uint32_t chunks13;       // ... and variant 13
   uint64_t chunk_wait_ticks;  // how long a chunk waits for its predecessor (wall-clock ticks of the device)
   uint32_t* d_err;         // device error word (PT_DEVERR_*), raised by a kernel that could not go on correctly
   uint32_t* h_err;         // pinned host copy, valid once ev_err has completed
@@ -273,6 +274,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->d_accel = nullptr;
   r->d_chunk = nullptr;
   r->chunks = 0;
+  r->chunks13 = 0;
   r->chunk_wait_ticks = 0;
   r->d_err = nullptr;
   r->h_err = nullptr;
@@ -318,6 +320,29 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     while (want >= 2 && want < PT_CHUNKS_MAX && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want *= 2;
     if (want >= 2 && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want = 0;
     r->chunks = want >= 2 ? (uint32_t)want : 0u;
+    // The pooled grid kernel (variant 13): 512-pixel workgroups, two resident per CU, 25 ms each at 1000 spheres x 256 spp --
+    // a 1024^2 frame is FOUR rounds of them and its time is whatever the last round's stragglers make it (measured: 98 or 107 ms
+    // from one frame to the next, profiles/r03/README.md).  Enough chunks for about thirty-two rounds, each at least 32 samples
+    // long (closed / open at 256 spp, chunks 1: 98-109 / 38.4 ms, 2: 101.5 / 36.4, 4: 97.3 / 35.4, 8: 96.0 / 35.1, 16: 97.9 / 36.3).
+    {
+      int want13 = o.chunks;
+      if (want13 == 0) {
+        const char* env = getenv("PT_CHUNKS");
+        if (env && *env) want13 = atoi(env);
+      }
+      if (want13 < 0 || want13 > PT_CHUNKS_MAX) want13 = 0;
+      if (want13 == 0 && r->tile_pixels > 0 && hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
+        const uint64_t resident = (uint64_t)prop.multiProcessorCount * 2u;  // workgroups
+        const uint64_t groups = ((uint64_t)r->tile_pixels + 511u) / 512u;
+        const uint64_t rounds = (groups + resident - 1) / resident;
+        want13 = rounds >= 32 ? 1 : (int)((32 + rounds - 1) / rounds);
+        if (want13 > 8) want13 = 8;
+        while (want13 >= 2 && r->spp / want13 < 32) want13 /= 2;
+      }
+      while (want13 >= 2 && want13 < PT_CHUNKS_MAX && (r->spp + want13 - 1) / want13 > PT_CHUNK_MAX_SAMPLES) want13 *= 2;
+      if (want13 >= 2 && (r->spp + want13 - 1) / want13 > PT_CHUNK_MAX_SAMPLES) want13 = 0;
+      r->chunks13 = want13 >= 2 ? (uint32_t)want13 : 0u;
+    }
     int khz = 0;  // s_memrealtime ticks per millisecond
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
     long wait_ms = 4000;
@@ -372,8 +397,11 @@ int pt_renderer_destroy(pt_renderer* r) {
 // Does a launch of this renderer with this variant and scene chain a pixel's samples through several workgroups?  Allocates the
 // hand-over buffer the first time the answer is yes; an allocation failure turns chunking off for good (it is a scheduling
 // aid, never a reason for a renderer not to work).
+static uint32_t chunks_of(const pt_renderer* r, int variant) { return variant == 13 ? r->chunks13 : r->chunks; }
+
 static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {
-  if (r->chunks < 2u || !pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
+  const uint32_t chunks = chunks_of(r, variant);
+  if (chunks < 2u || !pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, chunks))
     return false;
   if (r->d_chunk) return true;
   const size_t blocks = ((size_t)r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
@@ -381,6 +409,7 @@ static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {
     (void)hipGetLastError();  // not sticky: the launch that follows must not inherit it
     r->d_chunk = nullptr;
     r->chunks = 0;
+    r->chunks13 = 0;
     return false;
   }
   return true;
@@ -397,6 +426,7 @@ static int check_device_error(pt_renderer* r, bool wait) {
   *r->h_err = 0u;
   (void)hipMemset(r->d_err, 0, sizeof(uint32_t));
   r->chunks = 0;  // fall back to unchunked launches permanently: whatever broke the chain may do so again
+  r->chunks13 = 0;
   return pt_fail(PT_EKERNEL, "render: sample-chunk chain broken (device error word 0x%x): a workgroup waited %.0f ms for its "
                              "predecessor in vain; that frame is invalid, chunking is now off for this renderer", err,
                  (double)r->chunk_wait_ticks / 1e5);
@@ -433,7 +463,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->seed = r->opts.seed;
   // sample chunking: only for the kernels that chunk (reference configuration, variant 6), and only with a hand-over buffer
   const bool chunking = variant != PT_VARIANT_FAST && chunk_buffer(r, variant, n_spheres);
-  a->chunks = chunking ? r->chunks : 0u;
+  a->chunks = chunking ? chunks_of(r, variant) : 0u;
   a->chunk_state = chunking ? r->d_chunk : nullptr;
   a->chunk_flag = chunking ? r->d_chunk + (size_t)PT_CHUNK_WORDS * r->tile_pixels : nullptr;
   // a frame that fits the chip in at most two rounds of workgroups is mostly tail: its waves set their priority by progress
@@ -573,8 +603,9 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
   info->variant = variant;
   if (variant == 8 || variant == 9)
     info->grid_blocks = (int)(((uint64_t)r->tile_pixels * (variant == 8 ? 4 : 2) + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
-  if (!fast && r->chunks >= 2u && pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, r->chunks))
-    info->grid_blocks *= (int)r->chunks;  // sample chunking: that many workgroups per pixel block
+  if (!fast && chunks_of(r, variant) >= 2u &&
+      pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, chunks_of(r, variant)))
+    info->grid_blocks *= (int)chunks_of(r, variant);  // sample chunking: that many workgroups per pixel block
   info->num_vgprs = fa.numRegs;
   info->num_sgprs = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;

@@ -29,9 +29,15 @@ constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POO
 template <int VAR, int REFB, int RNG>
 constexpr int kMinWavesR = (VAR == 6 && REFB != 0 && RNG == PT_RNG_XORWOW) ? PT_REF_MIN_WAVES : kMinWaves<VAR>;
 
+// builds that can chain a pixel's samples through several workgroups of one launch (sample chunking, below): the reference-
+// configuration builds of variant 6 and the pooled grid kernel
+template <int VAR, int REFB>
+constexpr bool kChunkable = (VAR == 6 && REFB != 0) || VAR == 13;
+
 template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
 __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   constexpr bool REF = REFB != 0;
+  constexpr bool CHUNKS = kChunkable<VAR, REFB>;
   if constexpr (REF) {
     a.n_spheres = 9;
     a.max_bounces = REFB;
@@ -50,7 +56,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres) + 15) & ~(size_t)15);
   }
 
-  // Sample chunking (REF builds of variant 6): workgroup blockIdx.x = chunk * n_blocks + block renders samples
+  // Sample chunking (REF builds of variant 6, variant 13): workgroup blockIdx.x = chunk * n_blocks + block renders samples
   // [chunk * per, (chunk + 1) * per) of its 256 pixels and hands generator, sums and Welford accumulators to the next chunk
   // through chunk_state.  Forward progress ("sample chunking"): every dispatcher hands out its workgroups in
   // increasing index order, so by induction on the lowest unfinished index the predecessor of a waiting workgroup is resident
@@ -59,7 +65,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   // Same operations per pixel in the same order; what changes is that a frame of few, long workgroups becomes one of many
   // short ones (tools/shape_sweep.py: why).
   uint32_t block_id = blockIdx.x, chunk = 0u, n_chunks = 1u;
-  if constexpr (REF && VAR == 6) {
+  if constexpr (CHUNKS) {
     if (a.chunks > 1u) {
       const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
       n_chunks = a.chunks;
@@ -96,7 +102,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
   TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
   int i_begin = 0, i_end = a.spp;
-  if constexpr (REF && VAR == 6) {
+  if constexpr (CHUNKS) {
     if (n_chunks > 1u) {
       const int per = (a.spp + (int)n_chunks - 1) / (int)n_chunks;
       i_begin = (int)chunk * per;
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
 #endif
   }
 
-  int i = active ? i_begin : a.spp;  // inactive lanes trace nothing (i_begin: 0 unless this workgroup is a later chunk)
+  int i = active ? i_begin : i_end;  // inactive lanes trace nothing ([i_begin, i_end): all samples unless the frame is chunked)
   if constexpr (kRegen) {
     // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
     // per lane): the sample loop and the bounce loop are flattened into one per-lane state machine, so a
@@ -186,10 +192,11 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     F3 o = eye, d = eye;
     F3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);
     // issue priority by progress, as in the one-lane loop below (there: why); the progress of a wave is that of its first lane
-    const bool by_progress = a.spp >= PT_PRIO_MIN_SPP_REGEN;
-    const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
+    const int span = i_end - i_begin;  // this workgroup's samples
+    const bool by_progress = span >= PT_PRIO_MIN_SPP_REGEN;
+    const int q1 = i_begin + span / 4, q2 = i_begin + span / 2, q3 = i_end - span / 4;
     int last_band = -1;
-    while (i < a.spp) {
+    while (i < i_end) {
       if (by_progress) {
         const int iu = __builtin_amdgcn_readfirstlane(i);
         const int band = (iu >= q1 ? 1 : 0) + (iu >= q2 ? 1 : 0) + (iu >= q3 ? 1 : 0);
@@ -344,7 +351,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     }
     if (by_progress) __builtin_amdgcn_s_setprio(0);
   }
-  if constexpr (REF && VAR == 6) {
+  if constexpr (CHUNKS) {
     if (chunk + 1u < n_chunks) {  // not the last chunk: hand the pixel's state over and leave
       if (active) {
         auto st = [&](int w, uint32_t v) { a.chunk_state[(size_t)w * a.tile_pixels + tp] = v; };
@@ -853,7 +860,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 
 // does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
-  return variant == 6 && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar) && chunks > 1u &&
+  return ((variant == 6 && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar)) || variant == 13) && chunks > 1u &&
          chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks && (spp + (int)chunks - 1) / (int)chunks <= PT_CHUNK_MAX_SAMPLES;
 }
 
@@ -878,7 +885,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);
   const unsigned block = (unsigned)pt_kernel_block_threads(variant);
   unsigned grid = (unsigned)((lanes + block - 1) / block);
-  // sample chunking: only the reference-configuration build of variant 6 hands a pixel's state from workgroup to workgroup
+  // sample chunking: only the reference-configuration builds of variant 6 and variant 13 hand a pixel's state from workgroup to workgroup
   const bool chunked = pt_kernel_chunked(variant, a.n_spheres, a.max_bounces, a.planar != 0u, a.spp, a.chunks) && a.chunk_state && a.chunk_flag;
   b.chunks = chunked ? a.chunks : 0u;
   if (chunked) {

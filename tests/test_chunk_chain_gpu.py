@@ -38,6 +38,36 @@ def test_chunk_switch_and_lazy_buffer(pt, gpu, oracle):
     assert e.value.code == -1
 
 
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_pooled_grid_kernel_chunks(pt, gpu, oracle, rng):
+    """Variant 13 chains a pixel's samples through several 512-pixel workgroups too (its frames are few rounds of very long
+    workgroups): same bits for every chunk count, ragged sample counts and a ragged last workgroup, two frames with the generator
+    state carried over, closed and open scene."""
+    w, h, spp = 72, 40, 37
+    basis = pt.camera_basis(width=w, height=h)
+    blocks = (w * h + 511) // 512
+    for walls in (True, False):
+        scene = pt.scene_random(300, seed=31, with_walls=walls)
+        d_scene, n = pt.upload_scene(scene)
+        d_out = pt.DeviceBuffer(w * h * 56)
+        for chunks, per_block in ((1, 1), (2, 2), (5, 5), (8, 8), (16, 16)):
+            r = pt.Renderer(w, h, spp, variant=13, rng_mode=rng, chunks=chunks)
+            assert r.kernel_info(n)["grid_blocks"] == blocks * per_block, chunks
+            st = oracle.setup_random(w, h) if rng == 0 else None
+            for frame in range(2):
+                r.render(d_out.ptr, d_scene.ptr, n, basis)
+                ref = oracle.render(w, h, spp, spheres=scene, basis=basis, rng_mode=rng, rng_state=st, frame=frame)
+                assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref)), f"walls={walls} chunks={chunks} frame {frame}"
+            r.destroy()
+    # the automatic policy: a frame of few rounds of workgroups is chunked, a frame of many is not
+    r = pt.Renderer(1024, 1024, 256)
+    assert r.kernel_info(1000)["variant"] == 13 and r.kernel_info(1000)["grid_blocks"] == 8 * (1024 * 1024 // 512)
+    r.destroy()
+    r = pt.Renderer(4096, 4096, 64)
+    assert r.kernel_info(1000)["grid_blocks"] == 4096 * 4096 // 512  # 32768 workgroups = 64 rounds already
+    r.destroy()
+
+
 def test_broken_chunk_chain_is_an_error_not_a_frame(lab, gpu, oracle):
     w, h, spp = 64, 16, 640
     basis = lab.camera_basis(width=w, height=h)

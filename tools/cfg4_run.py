@@ -5,6 +5,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("PT_LIB_ALT"):
+    os.environ["PT_LIB_OVERRIDE"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-pathtrace_amd", "alt", os.environ["PT_LIB_ALT"], "libptcore.so")
 import __graft_entry__ as ge
 
 pt = ge.load_package()
