@@ -78,18 +78,23 @@ def cpu_baseline(oracle, cfg, spheres, basis, rows):
     w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
     cores = usable_cores()
     mb = cfg.get("max_bounces", 5)
+    reps = 1  # a configuration whose whole frame is a fraction of a second of CPU work (cfg5) is rendered several times
     if rows <= 0:  # size the sample for about 8 s of wall time per build from a short probe, capped at the full frame
-        probe_rows = max(1, 8 * 1024 * 1024 * 9 // (w * spp * max(9, len(spheres))))  # (a sample costs one test per sphere and bounce)
+        probe_rows = max(1, min(h - h // 2, 8 * 1024 * 1024 * 9 // (w * spp * max(9, len(spheres)))))  # (a sample costs one test per sphere and bounce)
         t = time.perf_counter()
         oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=h // 2, row_end=h // 2 + probe_rows, threads=cores, max_bounces=mb)
         rate = probe_rows * w * spp / (time.perf_counter() - t)
         rows = int(max(probe_rows, min(h, 8.0 * rate / (w * spp))))
+        if rows >= h:
+            reps = int(max(1, min(1000, 8.0 * rate / (w * h * spp))))
+    rows = min(rows, h)
     r0 = h // 2 - rows // 2
-    samples = rows * w * spp
+    samples = rows * w * spp * reps
 
     def timed(native):
         t = time.perf_counter()
-        oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores, native=native, max_bounces=mb)
+        for _ in range(reps):
+            oracle.render(w, h, spp, spheres=spheres, basis=basis, row_begin=r0, row_end=r0 + rows, threads=cores, native=native, max_bounces=mb)
         return time.perf_counter() - t
 
     dt = timed(False)
@@ -98,7 +103,8 @@ def cpu_baseline(oracle, cfg, spheres, basis, rows):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"rows {r0}..{r0 + rows - 1} of the {w}x{h} frame at {spp} spp ({samples / 1e6:.1f} Msamples, {dt:.1f} s wall), "
+        "sample": f"rows {r0}..{r0 + rows - 1} of the {w}x{h} frame at {spp} spp" + (f", rendered {reps} times" if reps > 1 else "") +
+                  f" ({samples / 1e6:.1f} Msamples, {dt:.1f} s wall), "
                   "gcc -O2 -ffp-contract=off (the parity build), pthreads over rows",
     }
     try:

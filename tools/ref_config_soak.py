@@ -31,7 +31,7 @@ for seed in range(first, first + n_cases):
     mode, spp = int(seed % 2), int(rng.integers(1, 13))
     mb = 8 if seed % 3 == 0 else 5  # the two bounce caps with a compile-time build (the reference's 5, the interactive 8)
     ref = oracle.render(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, threads=8, max_bounces=mb)
-    for v in (6, 8, None):
+    for v in (6, 8, 9, None):
         img, _ = pt.render_frame(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, variant=v, max_bounces=mb)
         neq = int((img.view(np.uint32) != ref.view(np.uint32)).sum())
         floats += img.size
@@ -39,5 +39,5 @@ for seed in range(first, first + n_cases):
             bad.append({"seed": seed, "variant": v, "floats_different": neq})
     if (seed - first) % 500 == 499:
         print(f"{seed - first + 1} cases, {floats} floats, {len(bad)} mismatching, {time.time()-t0:.0f} s", flush=True)
-print(json.dumps({"cases": n_cases, "first_seed": first, "variants": [6, 8, "auto"], "max_bounces": "5, every third case 8", "floats_compared": floats, "mismatches": bad}))
+print(json.dumps({"cases": n_cases, "first_seed": first, "variants": [6, 8, 9, "auto"], "max_bounces": "5, every third case 8", "floats_compared": floats, "mismatches": bad}))
 sys.exit(1 if bad else 0)
