@@ -38,12 +38,14 @@ namespace pt {
 
 // Grid resolution.  Round 3, with the sphere tests pooled (variant 13) a test costs a 64th of a pass and the balance moved
 // towards finer cells: 1000 spheres + walls at 32 spp, cells per sphere 0.5 / 1 / 2 / 3 / 4: 15.3 / 14.0 / 13.9 / 13.6 / 13.0 ms at
-// six waves per SIMD, 3: 12.7 and 4: 13.0 at four (profiles/r03/cfg4_ab.txt); variant 11 is indifferent (16.6-16.7 ms).
+// six waves per SIMD, 3: 12.7 and 4: 13.0 at four (profiles/r03/cfg4_ab.txt); variant 11 is indifferent (16.6-16.7 ms).  With sample
+// chunking on (steady frame times, 256 spp, closed | open ms): 2: 95.5 | 35.3, 2.25: 96.0 | 35.1, 2.5: 94.4 | 35.3, 2.75: 94.3 | 35.4,
+// 3: 95.6 | 35.1, 3.5: 96.3 | 35.4 -- flat within a percent (the steps are the cell counts per axis changing): 2.75.
 #ifndef PT_GRID_MAX_CELLS
 #define PT_GRID_MAX_CELLS 4096
 #endif
 #ifndef PT_GRID_CELLS_PER_SPHERE
-#define PT_GRID_CELLS_PER_SPHERE 3.0f
+#define PT_GRID_CELLS_PER_SPHERE 2.75f
 #endif
 constexpr int kGridMaxCells = PT_GRID_MAX_CELLS;
 #ifndef PT_GRID_TESTS_PER_TRIP
