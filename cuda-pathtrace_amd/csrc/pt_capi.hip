@@ -314,7 +314,12 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
     hipDeviceProp_t prop;
     if (want == 0 && r->spp >= 512 && r->tile_pixels > 0 && hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
       const uint64_t slots = (uint64_t)prop.multiProcessorCount * 4u * 4u * 64u;  // pixels resident at 4 waves per SIMD
-      if ((uint64_t)r->tile_pixels <= 8u * slots) want = PT_CHUNKS;
+      // The whole frame: two chunks (one hand-over per pixel; 49.95 -> 49.48 ms, eight: 49.40).  Row tiles -- what a rank of a multi-GPU
+      // run renders -- are one or two rounds of waves and gain more from more chunks (tools/chunk_tile.py, profiles/r03/README.md;
+      // chunks 1 / 2 / 4 / 6 / 8): 1/4 frame 13.03 / 13.31 / 12.71 / 13.03 / 12.62 ms, 1/2 frame 25.50 / 25.28 / 25.39 / 25.58 / 24.89,
+      // 3/16 frame 10.31 / 10.05 / 10.15 / 9.81 / 10.61 (the steps: chunks x waves per SIMD against the five resident).
+      if ((uint64_t)r->tile_pixels <= 8u * slots)
+        want = r->waves_per_simd > 8.5 ? PT_CHUNKS : (r->waves_per_simd > 3.25 ? PT_CHUNKS_TILE : PT_CHUNKS_SMALL_TILE);
     }
     // a chunk short enough that the worst chained wait stays far inside the wait limit: more chunks for very long frames
     while (want >= 2 && want < PT_CHUNKS_MAX && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want *= 2;

@@ -470,7 +470,20 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
   float* xl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * kRecWords);
   const int gbase = lane & ~(kSplit - 1);
 
-  const uint32_t gl = blockIdx.x * PT_BLOCK_THREADS + threadIdx.x;
+  // Sample chunking as in pixel_kernel (reference-configuration builds): workgroup blockIdx.x = chunk * n_blocks + block renders
+  // the samples [chunk * per, (chunk + 1) * per) of its 256 / kSplit pixels and hands their state to the next chunk through
+  // chunk_state (same 26-word layout: every lane stores the features it owns, lane 0 of a pixel the true generator state).
+  constexpr bool CHUNKS = REF;
+  uint32_t block_id = blockIdx.x, chunk = 0u, n_chunks = 1u;
+  if constexpr (CHUNKS) {
+    if (a.chunks > 1u) {
+      const uint32_t n_blocks = (uint32_t)(((uint64_t)a.tile_pixels * kSplit + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS);
+      n_chunks = a.chunks;
+      chunk = blockIdx.x / n_blocks;
+      block_id = blockIdx.x - chunk * n_blocks;
+    }
+  }
+  const uint32_t gl = block_id * PT_BLOCK_THREADS + threadIdx.x;
   const uint32_t tp = gl / kSplit;      // pixel index inside the tile
   const int s = (int)(gl % kSplit);     // sample slot; this lane accumulates features s*kOwn .. s*kOwn + kOwn - 1
   const bool active = tp < a.tile_pixels;
@@ -532,13 +545,54 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     w[q] = Welford{0, 0.0f, 0.0f};
   }
   bool seq = false;  // group-uniform: sequential mode after a failed speculation
-  int base = 0;      // group-uniform: first sample of the current round
+  int i_begin = 0, i_end = a.spp;  // this workgroup's samples (all of them unless the frame is chunked)
+  if constexpr (CHUNKS) {
+    if (n_chunks > 1u) {
+      int per = (a.spp + (int)n_chunks - 1) / (int)n_chunks;
+      per = (per + kSplit - 1) / kSplit * kSplit;  // whole rounds
+      i_begin = (int)chunk * per < a.spp ? (int)chunk * per : a.spp;
+      i_end = i_begin + per < a.spp ? i_begin + per : a.spp;
+      if (chunk > 0u) {
+        if (threadIdx.x == 0) {  // wait for the previous chunk of this block: bounded in time, giving up is an error (pixel_kernel)
+          const uint64_t t0 = wall_clock64();
+          uint32_t spins = 0;
+          while (__hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+            __builtin_amdgcn_s_sleep(32);
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > a.chunk_wait_ticks) {
+              if (a.err_word) atomicOr(a.err_word, PT_DEVERR_CHUNK_CHAIN);
+              break;
+            }
+          }
+        }
+        __syncthreads();
+        if (active) {
+          auto ld = [&](int w) { return __hip_atomic_load(a.chunk_state + (size_t)w * a.tile_pixels + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+          auto ldf = [&](int w) { return __uint_as_float(ld(w)); };
+#pragma unroll
+          for (int q = 0; q < kOwn; q++) {
+            const int f = s * kOwn + q;  // 0 colour, 1 normal, 2 albedo, 3 depth
+            sum0[q] = ldf(f < 3 ? 3 * f : 9);
+            sum1[q] = f < 3 ? ldf(3 * f + 1) : 0.0f;
+            sum2[q] = f < 3 ? ldf(3 * f + 2) : 0.0f;
+            w[q] = Welford{(int)ld(f == 0 ? 10 : 11), ldf(12 + 2 * f), ldf(13 + 2 * f)};
+          }
+          if constexpr (RNG == PT_RNG_XORWOW) {  // the pixel's true state after sample i_begin - 1; lane s starts s samples further on
+            rng.st = Xorwow{ld(20), ld(21), ld(22), ld(23), ld(24), ld(25)};
+            final_state = rng.st;
+            xorwow_skip(rng.st, s * D);
+          }
+        }
+      }
+    }
+  }
+  int base = i_begin;  // group-uniform: first sample of the current round
 
   // issue priority by progress, as in pixel_kernel (there: why); the progress of a wave is that of its first pixel group
-  const bool by_progress = a.spp >= PT_PRIO_MIN_SPP;
-  const int q1 = a.spp / 4, q2 = a.spp / 2, q3 = a.spp - a.spp / 4;
+  const int span = i_end - i_begin;
+  const bool by_progress = a.spp >= PT_PRIO_MIN_SPP && span >= 4;
+  const int q1 = i_begin + span / 4, q2 = i_begin + span / 2, q3 = i_end - span / 4;
   int last_band = -1;
-  while (base < a.spp) {
+  while (base < i_end) {
     if (by_progress) {
       const int bu = __builtin_amdgcn_readfirstlane(base);
       const int band = (bu >= q1 ? 1 : 0) + (bu >= q2 ? 1 : 0) + (bu >= q3 ? 1 : 0);
@@ -551,7 +605,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
       }
     }
     const int k = seq ? base : base + s;
-    const bool mine = active && (!seq || s == 0) && k < a.spp;
+    const bool mine = active && (!seq || s == 0) && k < i_end;
     PathResult res[1];
     res[0].color = res[0].normal0 = res[0].albedo0 = mk3(0.0f, 0.0f, 0.0f);
     res[0].t0 = 0.0f;
@@ -645,7 +699,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
           final_state = Xorwow{ru[0], ru[1], ru[2], ru[3], ru[4], ru[5]};
         }
         const int kj = seq ? base : base + j;
-        if (valid & esc & !seq & (kj < a.spp - 1)) failed = true;  // later speculative states are wrong
+        if (valid & esc & !seq & (kj < i_end - 1)) failed = true;  // later speculative states are wrong
       }
       consumed += valid ? 1 : 0;
     }
@@ -671,6 +725,38 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     }
   }
   if (by_progress) __builtin_amdgcn_s_setprio(0);
+
+  if constexpr (CHUNKS) {
+    if (chunk + 1u < n_chunks) {  // not the last chunk: hand the pixel's state over and leave
+      if (active) {
+        auto st = [&](int wd, uint32_t v) { a.chunk_state[(size_t)wd * a.tile_pixels + tp] = v; };
+        auto stf = [&](int wd, float v) { st(wd, __float_as_uint(v)); };
+#pragma unroll
+        for (int q = 0; q < kOwn; q++) {
+          const int f = s * kOwn + q;
+          if (f < 3) {
+            stf(3 * f, sum0[q]); stf(3 * f + 1, sum1[q]); stf(3 * f + 2, sum2[q]);
+          } else {
+            stf(9, sum0[q]);
+          }
+          if (f < 2) st(10 + f, (uint32_t)w[q].n);  // the three first-hit accumulators count together: the normal's stands for them
+          stf(12 + 2 * f, w[q].mean);
+          stf(13 + 2 * f, w[q].M2);
+        }
+        if constexpr (RNG == PT_RNG_XORWOW) {
+          if (s == 0) {
+            st(20, final_state.d); st(21, final_state.v0); st(22, final_state.v1); st(23, final_state.v2); st(24, final_state.v3); st(25, final_state.v4);
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_store(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
 
   if (active) {  // :234-254, each lane stores its feature
     const float fs = (float)a.spp;
@@ -860,7 +946,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 
 // does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
-  return ((variant == 6 && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar)) || variant == 13) && chunks > 1u &&
+  return (((variant == 6 || variant == 8 || variant == 9) && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar)) || variant == 13) && chunks > 1u &&
          chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks && (spp + (int)chunks - 1) / (int)chunks <= PT_CHUNK_MAX_SAMPLES;
 }
 

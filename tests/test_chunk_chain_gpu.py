@@ -23,7 +23,7 @@ def test_chunk_switch_and_lazy_buffer(pt, gpu, oracle):
     d_scene, n = pt.upload_scene(pt.scene_cornell())
     d_out = pt.DeviceBuffer(w * h * 56)
     blocks = (w * h + 255) // 256
-    for chunks, per_block in ((1, 1), (2, 2), (4, 4), (8, 8), (16, 16), (0, 2)):
+    for chunks, per_block in ((1, 1), (2, 2), (4, 4), (8, 8), (16, 16), (0, 6)):
         r = pt.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=chunks)
         assert r.kernel_info(n)["grid_blocks"] == blocks * per_block, chunks
         r.render(d_out.ptr, d_scene.ptr, n, basis)
