@@ -56,7 +56,8 @@ struct pt_renderer {
   uint32_t* d_chunk;       // sample chunking (pt_kernel.hip): PT_CHUNK_WORDS words per tile pixel + one flag per pixel block; allocated
                            // by the first launch that chunks (never for renderers whose kernels do not), or null
   uint32_t chunks;         // how many chunks a frame of this renderer is split into when the kernel supports it (0 = off): variant 6 ...
-  uint32_t chunks13;       // ... and variant 13
+  uint32_t chunks13;       // ... variant 13 ...
+  uint32_t chunks_split;   // ... and the split kernels (variants 8, 9)
   uint64_t chunk_wait_ticks;  // how long a chunk waits for its predecessor (wall-clock ticks of the device)
   uint32_t* d_err;         // device error word (PT_DEVERR_*), raised by a kernel that could not go on correctly
   uint32_t* h_err;         // pinned host copy, valid once ev_err has completed
@@ -98,10 +99,12 @@ static int mark_last(pt_renderer* r, hipStream_t stream) {
 #define PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX 5
 
 // the split kernel (8, 9) or 6 for a small xorwow tile of the reference configuration, by one-lane waves per SIMD
+// (with sample chunking in the split kernels too -- chunks 1 / 4 / 5, tools/chunk_tile.py: variant 9 w = 2: 6.94 / 6.81 / 6.76 ms,
+// 2.5: 9.67 / 8.43 / 8.47, 3.5: 11.95 / 11.79 / 11.72, 1: 4.68 / 4.39 / 4.40; variant 8 w = 1: 3.84 / 3.68 / 3.74, 2.5: 9.11 / 9.08 / 9.12 --
+// the two-lane kernel also takes the band around 2.5)
 static int small_tile_variant(double w) {
   if (w <= 1.25) return 8;
-  if (w <= 2.0) return 9;
-  if (w < 2.75) return 8;
+  if (w < 2.75) return 9;
   if (w <= 3.0) return PT_DEFAULT_VARIANT;
   if (w <= 3.5) return 9;
   return PT_DEFAULT_VARIANT;
@@ -275,6 +278,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->d_chunk = nullptr;
   r->chunks = 0;
   r->chunks13 = 0;
+  r->chunks_split = 0;
   r->chunk_wait_ticks = 0;
   r->d_err = nullptr;
   r->h_err = nullptr;
@@ -348,6 +352,19 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
       if (want13 >= 2 && (r->spp + want13 - 1) / want13 > PT_CHUNK_MAX_SAMPLES) want13 = 0;
       r->chunks13 = want13 >= 2 ? (uint32_t)want13 : 0u;
     }
+    // the split kernels (small tiles of the reference configuration: one or two rounds of waves by construction): four chunks
+    // (numbers at small_tile_variant)
+    {
+      int ws = o.chunks;
+      if (ws == 0) {
+        const char* env = getenv("PT_CHUNKS");
+        if (env && *env) ws = atoi(env);
+      }
+      if (ws == 0 && r->spp >= 512) ws = PT_CHUNKS_SPLIT;
+      while (ws >= 2 && ws < PT_CHUNKS_MAX && (r->spp + ws - 1) / ws > PT_CHUNK_MAX_SAMPLES) ws *= 2;
+      if (ws < 2 || ws > PT_CHUNKS_MAX || (r->spp + ws - 1) / ws > PT_CHUNK_MAX_SAMPLES) ws = 0;
+      r->chunks_split = (uint32_t)ws;
+    }
     int khz = 0;  // s_memrealtime ticks per millisecond
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
     long wait_ms = 4000;
@@ -402,19 +419,22 @@ int pt_renderer_destroy(pt_renderer* r) {
 // Does a launch of this renderer with this variant and scene chain a pixel's samples through several workgroups?  Allocates the
 // hand-over buffer the first time the answer is yes; an allocation failure turns chunking off for good (it is a scheduling
 // aid, never a reason for a renderer not to work).
-static uint32_t chunks_of(const pt_renderer* r, int variant) { return variant == 13 ? r->chunks13 : r->chunks; }
+static uint32_t chunks_of(const pt_renderer* r, int variant) {
+  return variant == 13 ? r->chunks13 : (variant == 8 || variant == 9) ? r->chunks_split : r->chunks;
+}
 
 static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {
   const uint32_t chunks = chunks_of(r, variant);
   if (chunks < 2u || !pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, chunks))
     return false;
   if (r->d_chunk) return true;
-  const size_t blocks = ((size_t)r->tile_pixels + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;
+  const size_t blocks = ((size_t)r->tile_pixels * 4 + PT_BLOCK_THREADS - 1) / PT_BLOCK_THREADS;  // (the four-lane kernel has the most pixel blocks)
   if (hipMalloc((void**)&r->d_chunk, ((size_t)PT_CHUNK_WORDS * r->tile_pixels + blocks) * sizeof(uint32_t)) != hipSuccess) {
     (void)hipGetLastError();  // not sticky: the launch that follows must not inherit it
     r->d_chunk = nullptr;
     r->chunks = 0;
     r->chunks13 = 0;
+    r->chunks_split = 0;
     return false;
   }
   return true;
@@ -432,6 +452,7 @@ static int check_device_error(pt_renderer* r, bool wait) {
   (void)hipMemset(r->d_err, 0, sizeof(uint32_t));
   r->chunks = 0;  // fall back to unchunked launches permanently: whatever broke the chain may do so again
   r->chunks13 = 0;
+  r->chunks_split = 0;
   return pt_fail(PT_EKERNEL, "render: sample-chunk chain broken (device error word 0x%x): a workgroup waited %.0f ms for its "
                              "predecessor in vain; that frame is invalid, chunking is now off for this renderer", err,
                  (double)r->chunk_wait_ticks / 1e5);

@@ -125,6 +125,7 @@ struct PixelKernelArgs {
 #endif
 #define PT_CHUNKS_TILE 8        // ... on tiles of at most 8.5 one-lane waves per SIMD (half a 1024^2 frame and less), pt_capi.hip
 #define PT_CHUNKS_SMALL_TILE 6  // ... and of at most 3.25
+#define PT_CHUNKS_SPLIT 4       // ... in the split kernels (variants 8, 9)
 #define PT_CHUNKS_MAX 16
 // A chunk may only be as long as keeps the worst chained wait (all chunks of a block co-resident: chunk k waits k chunk
 // durations) far inside the wait limit: at most this many samples per chunk (about 50 ms of kernel time on an MI355X)

@@ -30,7 +30,10 @@ def test_chunk_switch_and_lazy_buffer(pt, gpu, oracle):
         assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref)), f"chunks={chunks}"
         r.destroy()
     # kernels that never chunk report one workgroup per pixel block whatever the option says
-    r = pt.Renderer(w, h, spp, variant=8, chunks=8)
+    r = pt.Renderer(w, h, spp, variant=10, chunks=8)
+    assert r.kernel_info(n)["grid_blocks"] == blocks
+    r.destroy()
+    r = pt.Renderer(w, h, spp, variant=8, chunks=8, max_bounces=6)  # no reference-configuration build for 6 bounces
     assert r.kernel_info(n)["grid_blocks"] == (w * h * 4 + 255) // 256
     r.destroy()
     with pytest.raises(pt.PtError) as e:
@@ -66,6 +69,35 @@ def test_pooled_grid_kernel_chunks(pt, gpu, oracle, rng):
     r = pt.Renderer(4096, 4096, 64)
     assert r.kernel_info(1000)["grid_blocks"] == 4096 * 4096 // 512  # 32768 workgroups = 64 rounds already
     r.destroy()
+
+
+@pytest.mark.parametrize("variant", [8, 9], ids=["four_lanes", "two_lanes"])
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_split_kernels_chunks(pt, gpu, oracle, rng, variant):
+    """Variants 8 and 9 (several lanes per pixel, speculative generator skip-ahead) chain their samples through workgroups as
+    well: every lane hands over the features it owns, lane 0 the pixel's TRUE generator state -- also when a speculation
+    failed inside the chunk (open scene) and when the sample count is not a multiple of the lanes per pixel or of the chunks."""
+    w, h = 40, 24
+    basis = pt.camera_basis(width=w, height=h)
+    lanes = 4 if variant == 8 else 2
+    blocks = (w * h * lanes + 255) // 256
+    for name, scene in (("closed", pt.scene_cornell()), ("open", pt.scene_cornell()[[0, 2, 4, 6, 7, 8, 1, 3, 5]][:9])):
+        if name == "open":
+            scene = scene.copy()
+            scene["radius"][6:] = 1.0  # three of the walls become small spheres: paths escape, speculations fail (still 9 spheres: REF build)
+        d_scene, n = pt.upload_scene(scene)
+        d_out = pt.DeviceBuffer(w * h * 56)
+        for spp, chunks in ((37, 2), (37, 5), (64, 4), (13, 3)):
+            r = pt.Renderer(w, h, spp, variant=variant, rng_mode=rng, chunks=chunks)
+            assert r.kernel_info(n)["grid_blocks"] == blocks * chunks, (spp, chunks)
+            st = oracle.setup_random(w, h) if rng == 0 else None
+            for frame in range(2):
+                r.render(d_out.ptr, d_scene.ptr, n, basis)
+                ref = oracle.render(w, h, spp, spheres=scene, basis=basis, rng_mode=rng, rng_state=st, frame=frame)
+                assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref)), f"{name} spp {spp} chunks {chunks} frame {frame}"
+                if rng == 0:
+                    assert np.array_equal(r.get_rng_state(), st), f"{name} spp {spp} chunks {chunks}: generator state after frame {frame}"
+            r.destroy()
 
 
 def test_broken_chunk_chain_is_an_error_not_a_frame(lab, gpu, oracle):

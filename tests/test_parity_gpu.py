@@ -531,7 +531,7 @@ def test_automatic_variant_policy(pt, oracle, gpu):
     quarter = pt.Renderer(1024, 1024, 1024, row_begin=0, row_end=256)
     assert quarter.kernel_info(9)["variant"] == 6
     quarter.destroy()
-    for rows, expect in ((64, 8), (128, 9), (160, 8), (192, 6), (224, 9)):  # 1, 2, 2.5, 3, 3.5 one-lane waves per SIMD
+    for rows, expect in ((64, 8), (128, 9), (160, 9), (192, 6), (224, 9)):  # 1, 2, 2.5, 3, 3.5 one-lane waves per SIMD
         r = pt.Renderer(1024, 1024, 1024, row_begin=0, row_end=rows)
         assert r.kernel_info(9)["variant"] == expect, rows
         r.destroy()

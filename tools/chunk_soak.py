@@ -33,7 +33,7 @@ for seed in range(first, first + n_cases):
     r0 = int(rng.integers(0, size // 2))
     r1 = int(rng.integers(r0 + 1, size + 1))
     ref = oracle.render(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, threads=8, row_begin=r0, row_end=r1)
-    for v in (6,):
+    for v in (6, 8, 9):
         img, _ = pt.render_frame(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, variant=v, row_begin=r0, row_end=r1)
         neq = int((img.view(np.uint32) != ref.view(np.uint32)).sum())
         floats += img.size
@@ -41,5 +41,5 @@ for seed in range(first, first + n_cases):
             bad.append({"seed": seed, "variant": v, "floats_different": neq})
     if (seed - first) % 50 == 49:
         print(f"{seed - first + 1} cases, {floats} floats, {len(bad)} mismatching, {time.time()-t0:.0f} s", flush=True)
-print(json.dumps({"cases": n_cases, "first_seed": first, "variants": [6], "spp": "512..900", "floats_compared": floats, "mismatches": bad}))
+print(json.dumps({"cases": n_cases, "first_seed": first, "variants": [6, 8, 9], "spp": "512..900", "floats_compared": floats, "mismatches": bad}))
 sys.exit(1 if bad else 0)
