@@ -248,9 +248,18 @@ __device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 
   // c == 0 (or a root too close to 0 to classify) is flagged below.
   const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));  // c < 0 ? +inf : -inf
   const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
-  const uint32_t w = __float_as_uint(dacc) | __float_as_uint(T);
-  uint32_t key = (w & 0x80000000u) | __float_as_uint(T);
-  key = (key & ~imask) | (uint32_t)i;
+  // key = T's bits with the index in the low bits and the sign bit set if dacc or T is negative (= no candidate), written as the
+  // two v_and_or_b32 it is (the compiler made four instructions of "sign of (dacc | T), or T, mask, or index")
+  uint32_t key;
+  if (__builtin_constant_p(i) && __builtin_constant_p(imask) && imask <= 63u && i >= 0 && i <= 63) {
+    // unrolled builds: mask and index are inline constants of ONE v_and_or_b32, the sign of dacc enters with a second one
+    // (left to itself the compiler emits v_and, v_and, v_or3 -- and a v_or for dacc | T before the rewrite)
+    uint32_t t1;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t1) : "v"(__float_as_uint(T)), "i"((int)~imask), "i"(i));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(dacc)), "s"(0x80000000u), "v"(t1));
+  } else {
+    key = (__float_as_uint(dacc) & 0x80000000u) | ((__float_as_uint(T) & ~imask) | (uint32_t)i);
+  }
   // When can the estimate not be trusted?  Only when num = ac + e has lost its leading digits (the small root then has no
   // relative accuracy, and its SIGN -- which root the reference returns -- is open) or ac is zero: since |e| <= 2^-24 hh,
   // |ac| > 2^-23 hh leaves |num| > |ac| / 2.  One fma and one compare; the floor covers hh below the normal range, where
