@@ -18,6 +18,24 @@ struct F3 {
 };
 
 __device__ __forceinline__ F3 mk3(float x, float y, float z) { return F3{x, y, z}; }
+
+// v_bitop3_b32: ANY bitwise function of three words in one instruction, and the only three-operand bit instruction that issues at
+// the FULL rate on gfx950 (2.2 cycles per wave64; v_bfi_b32, v_and_or_b32, v_or3_b32, every shift, v_cndmask_b32: 4.1 --
+// tools/ubench/valu_clock.hip, profiles/r03/valu_clock_bit_ops.txt).  TT is the truth table with a = 0xF0, b = 0xCC, c = 0xAA,
+// e.g. (a & c) | (b & ~c) = 0xE4.  The compiler picks it for some and/or/xor trees and v_bfi/v_and_or for others, so the
+// hot path asks for it by name.
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+// copysignf(mag, -sgn): (a & c) | (~b & ~c)
+__device__ __forceinline__ float copysign_neg_b3(float mag, float sgn) {
+  return __uint_as_float(bitop3<0xB1>(__float_as_uint(mag), __float_as_uint(sgn), 0x7FFFFFFFu));
+}
+// copysignf(mag, sgn) (the library form compiles to the half-rate v_bfi_b32)
+__device__ __forceinline__ float copysign_b3(float mag, float sgn) {
+  return __uint_as_float(bitop3<0xE4>(__float_as_uint(mag), __float_as_uint(sgn), 0x7FFFFFFFu));
+}
 __device__ __forceinline__ F3 operator+(F3 a, F3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -60,7 +78,8 @@ __device__ __forceinline__ uint32_t xorwow_next(Xorwow& s) {
   s.v1 = s.v2;
   s.v2 = s.v3;
   s.v3 = s.v4;
-  s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+  // (v4 ^ (v4 << 4)) ^ (t ^ (t << 1)): the same word from one shift (half rate), one add (t << 1 = t + t), one three-way xor
+  s.v4 = bitop3<0x96>(s.v4 ^ (s.v4 << 4), t, t + t);
   s.d += 362437u;
   return s.v4 + s.d;
 }

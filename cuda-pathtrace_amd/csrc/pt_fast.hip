@@ -55,13 +55,13 @@ __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, cons
   const float c = (off.x * off.x + off.y * off.y + off.z * off.z) - g.w;
   disc = fmaf(h, h, -a * c);                                                         // det / 4
   const float s = __builtin_amdgcn_sqrtf(disc);                                      // NaN when there is no real root
-  const float q = h + copysignf(s, h);
+  const float q = h + copysign_b3(s, h);
   const float t_big = -q * inv_a;                       // the root of larger magnitude
   const float t_small = -c * __builtin_amdgcn_rcpf(q);  // the other one: their product is c / a
   // The reference returns the smaller root if it is positive, else the larger (:82-88).  Origin inside the sphere
   // (c < 0): opposite signs, that is the positive = larger one; outside: same sign, the smaller one (if it is
   // negative so is the other and the caller rejects it).  One median with +-inf does both.
-  const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));  // c < 0 ? +inf : -inf
+  const float K = __uint_as_float(bitop3<0x6C>(__float_as_uint(c), 0xFF800000u, 0x80000000u));  // c < 0 ? +inf : -inf
   return __builtin_amdgcn_fmed3f(t_big, t_small, K);
 }
 

@@ -430,16 +430,18 @@ __device__ __forceinline__ bool near2_test(Near2& s, const float4 g, int i, F3 o
   // a sphere can sit in several cells: the current leader must not be entered again as its own runner-up
   const bool cand = ((int)__float_as_uint(dacc) >= 0) & !((i == s.i1) & (s.T1 < INF));
   const float sq = __builtin_amdgcn_sqrtf(dacc);
-  const float q = b + copysignf(sq, b);
   const float e = fmaf(b, b, -bb);
   const float num = a4c + e;
-  const float TA = -q;
-  const float TB = -num * __builtin_amdgcn_rcpf(q);
-  // the root the reference returns: origin inside (c < 0) the larger, outside the smaller (screen_sphere, pt_intersect.h)
-  const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));
-  const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
+  const float TA = copysign_neg_b3(sq, b) - b;  // -q, q = b + copysign(sq, b) (screen_sphere_oc)
+  const float TB = num * __builtin_amdgcn_rcpf(TA);
+  // the root the reference returns -- the smaller positive one -- is the unsigned minimum of the two bit patterns, and a word
+  // with the sign bit set (or a NaN's bits) when there is none (screen_sphere_oc, pt_intersect.h): one unsigned compare with the
+  // limit's bits is "positive, finite and below the limit"
+  const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
+  const uint32_t tbits = ta < tb ? ta : tb;
+  const float T = __uint_as_float(tbits);
   const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);  // num = a4c + e keeps its leading digits (screen_sphere_oc)
-  const bool ok = cand & sure & ((int)__float_as_uint(T) >= 0) & (T < Tlim_hi);
+  const bool ok = cand & sure & (tbits < __float_as_uint(Tlim_hi));
   const float Te = ok ? T : INF;
   s.i1 = Te < s.T1 ? i : s.i1;
   s.T2 = __builtin_amdgcn_fmed3f(s.T1, s.T2, Te);  // the second smallest of {T1, T2, Te} (T1 <= T2 always)
@@ -945,15 +947,15 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
       const float dacc = fmaf(-ra4, cc, bb);
       const bool cand = valid & ((int)__float_as_uint(dacc) >= 0);
       const float sq = __builtin_amdgcn_sqrtf(dacc);
-      const float q = b + copysignf(sq, b);
       const float ee = fmaf(b, b, -bb);
       const float num = a4c + ee;
-      const float TA = -q;
-      const float TB = -num * __builtin_amdgcn_rcpf(q);
-      const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(cc) & 0x80000000u));
-      float T = __builtin_amdgcn_fmed3f(TA, TB, K);
+      const float TA = copysign_neg_b3(sq, b) - b;  // -q (near2_test)
+      const float TB = num * __builtin_amdgcn_rcpf(TA);
+      const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
+      const uint32_t tbits = ta < tb ? ta : tb;  // the smaller positive root's bits, sign bit set or NaN bits if none (near2_test)
+      float T = __uint_as_float(tbits);
       const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);
-      bool ok = cand & sure & ((int)__float_as_uint(T) >= 0) & (T < rTlim_hi);
+      bool ok = cand & sure & (tbits < __float_as_uint(rTlim_hi));
       if (__builtin_expect(cand & !sure, 0)) {  // near2_exact: the reference's own test, 2a*t in place of the estimate
         float t = 0.0f;
         const float ra = 0.25f * ra4;

@@ -67,7 +67,7 @@ PT_UNROLL(PT_SCREEN_UNROLL)
     const float det = bb - a4c;
     const float dacc = fmaf(-rc.a4, c, bb);
     const float s = __builtin_amdgcn_sqrtf(fmaxf(dacc, 0.0f));
-    const float q = b + copysignf(s, b);
+    const float q = b + copysign_b3(s, b);
     const float TA = -q;  // = -b - sign(b)*s: the contract's own expression, no cancellation
     // the other root -b + sign(b)*s = (s*s - b*b)/q, and s*s = bb - 4ac with the ROUNDED bb of the
     // contract: s*s - b*b = -(4ac + (b*b - bb)); e = b*b - bb is exact in one fma.
@@ -236,30 +236,28 @@ __device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 
   // bb - 4a*c once; the two can differ in sign only when |bb - 4ac| <= 2^-24 |4ac|, and then the winner's exact
   // step decides (see the note on `unsure` below), so det itself need not be formed here.
   const float dacc = fmaf(-rc.a, c, hh);           // one rounding of the contract's exact discriminant (bb - 4ac) / 4
-  const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the sign bit of dacc rejects it below
-  const float q = h + copysignf(s, h);             // |h| + s with h's sign: no cancellation
+  const float s = __builtin_amdgcn_sqrtf(dacc);    // NaN for dacc < 0: the key below is then no candidate
   const float e = fmaf(h, h, -hh);                 // h*h - hh exactly: the rounding error of the contract's bb (/ 4)
   const float num = ac + e;
-  const float TA = -q;                             // root -b - sign(b) s (x 2a), halved: a * t
-  const float TB = -num * __builtin_amdgcn_rcpf(q);  // root -b + sign(b) s = -(4ac + (b*b - bb)) / q (x 2a), halved
-  // The reference returns tNear if it is positive, else tFar.  Origin inside the sphere (c < 0): the roots
-  // have opposite signs, that is the larger one.  Outside (c > 0): same sign, the smaller one (if it is
-  // negative so is the other and the candidate is rejected either way).  One median with +-inf does both;
-  // c == 0 (or a root too close to 0 to classify) is flagged below.
-  const float K = __uint_as_float(0x7F800000u | (~__float_as_uint(c) & 0x80000000u));  // c < 0 ? +inf : -inf
-  const float T = __builtin_amdgcn_fmed3f(TA, TB, K);
-  // key = T's bits with the index in the low bits and the sign bit set if dacc or T is negative (= no candidate), written as the
-  // two v_and_or_b32 it is (the compiler made four instructions of "sign of (dacc | T), or T, mask, or index")
-  uint32_t key;
-  if (__builtin_constant_p(i) && __builtin_constant_p(imask) && imask <= 63u && i >= 0 && i <= 63) {
-    // unrolled builds: mask and index are inline constants of ONE v_and_or_b32, the sign of dacc enters with a second one
-    // (left to itself the compiler emits v_and, v_and, v_or3 -- and a v_or for dacc | T before the rewrite)
-    uint32_t t1;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t1) : "v"(__float_as_uint(T)), "i"((int)~imask), "i"(i));
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(dacc)), "s"(0x80000000u), "v"(t1));
-  } else {
-    key = (__float_as_uint(dacc) & 0x80000000u) | ((__float_as_uint(T) & ~imask) | (uint32_t)i);
-  }
+  // q = h + copysign(s, h) = |h| + s with h's sign (no cancellation); the roots (x 2a, halved: a * t) are -q and -num / q.
+  // -q is formed directly (s with the sign of -h, minus h: the same float, zero signs included, since both terms share a sign),
+  // so that its BITS are at hand for the unsigned minimum below without a negation of their own.
+  const float TA = copysign_neg_b3(s, h) - h;      // root -b - sign(b) s
+  const float TB = num * __builtin_amdgcn_rcpf(TA);  // root -b + sign(b) s = (4ac + (b*b - bb)) / -q
+  // The reference returns the smaller root if both are positive, else the positive one, else a non-positive number that its
+  // caller discards (pathtrace.cu:82-88,99).  For float bit patterns that is ONE unsigned minimum: positive floats order like
+  // their bits and every negative one (sign bit set) lies above all of them -- min(bits(TA), bits(TB)) is the smaller positive
+  // estimate, and a word with the sign bit set exactly when neither is positive.  (Until round 3: a median of TA, TB and an
+  // infinity with the sign of -c, two instructions.)  The estimates' signs are the roots' signs unless the small root is too
+  // close to 0 to classify, which is flagged below.  A negative dacc needs no bit of its own: v_sqrt_f32 of a negative number
+  // is NaN and q, TA, TB with it -- bits above 0x7F800000 with either sign, which rank behind every T below the limit and fail
+  // `has`.  (A negative DENORMAL dacc may be flushed to -0 by the square root: the sphere is then ranked as a tangent hit, which
+  // only matters if it wins, and the winner's exact step evaluates the reference's own det -- wrongly ACCEPTING a candidate is
+  // always safe here, only wrongly rejecting one is not.)
+  const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
+  const uint32_t tbits = ta < tb ? ta : tb;
+  // key = the estimate's bits with the index in the low bits; a set sign bit = no candidate
+  const uint32_t key = bitop3<0xBA>(tbits, imask, (uint32_t)i);  // (T & ~imask) | i, full rate (v_and_or_b32 is not)
   // When can the estimate not be trusted?  Only when num = ac + e has lost its leading digits (the small root then has no
   // relative accuracy, and its SIGN -- which root the reference returns -- is open) or ac is zero: since |e| <= 2^-24 hh,
   // |ac| > 2^-23 hh leaves |num| > |ac| / 2.  One fma and one compare; the floor covers hh below the normal range, where
@@ -456,14 +454,15 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
     const bool cand = (int)__float_as_uint(h.dacc) >= 0;
     if (__builtin_amdgcn_ballot_w64(cand) == 0) return;
     const float s = __builtin_amdgcn_sqrtf(h.dacc);
-    const float q = h.b + copysignf(s, h.b);
     const float e = fmaf(h.b, h.b, -h.bb);
     const float num = h.a4c + e;
-    const float TA = -q;
-    const float TB = -num * __builtin_amdgcn_rcpf(q);
-    const float lo = fminf(TA, TB), hi = fmaxf(TA, TB);
-    const float T = lo > 0.0f ? lo : hi;
-    const bool ok = ((int)(__float_as_uint(h.dacc) | __float_as_uint(T)) >= 0) & (T < Tlim_hi);
+    const float TA = copysign_neg_b3(s, h.b) - h.b;  // -q, q = b + copysign(s, b) (screen_sphere_oc)
+    const float TB = num * __builtin_amdgcn_rcpf(TA);
+    // the smaller positive root = the unsigned minimum of the bit patterns; sign bit set / NaN bits (dacc < 0) if there is none
+    const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
+    const uint32_t tbits = ta < tb ? ta : tb;
+    const float T = __uint_as_float(tbits);
+    const bool ok = tbits < __float_as_uint(Tlim_hi);
     unsure = unsure | (cand & !(fabsf(h.a4c) > fmaf(h.bb, 1.1920929e-07f, 1e-30f)));  // see screen_sphere_oc
     const float Te = ok ? T : INF;
     const bool c1 = Te < T1, c2 = Te < T2;

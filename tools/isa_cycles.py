@@ -2,7 +2,7 @@
 """Static issue-cycle model of a kernel's hot loop from its ISA, with the per-class costs measured by
 tools/ubench/valu_clock (cycles a wave64 instruction holds its SIMD at full occupancy):
   full-rate (f32 add/sub/mul/fma, mov, and/or/xor/not, 32-bit integer add/sub)  ~2
-  half-rate (compare, cndmask, min/max/med3, bfi/bitop3, shifts, cvt, mul_lo/hi, every FP64 add/mul/fma, packed f32)  4
+  half-rate (compare, cndmask, min/max/med3, bfi/and_or/or3, shifts, cvt, mul_lo/hi, every FP64 add/mul/fma, packed f32)  4
   f32 transcendentals (rcp, rsq, sqrt, ...)  8;   f64 transcendentals  16
 Usage: isa_cycles.py file.s kernel_symbol_substring first_line last_line   (line numbers inside the kernel, 1-based)
 Prints cycles by class and the most expensive mnemonics."""
@@ -11,7 +11,7 @@ import re
 import sys
 
 FULL = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mov_b32",
-        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_accvgpr", "v_mov_b64")
+        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_accvgpr", "v_mov_b64")
 T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32")
 T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
 

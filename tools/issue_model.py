@@ -3,7 +3,7 @@
 rate of each instruction class, against the SIMD cycles the kernel TOOK (GRBM_GUI_ACTIVE of the counter run).
 
   full-rate  (v_add/sub/mul/fma_f32, v_mov, and/or/xor/not, 32-bit integer add/sub)                       2 cycles
-  half-rate  (compare, cndmask, min/max/med3, bfi/bitop3, shifts, cvt, every FP64 add/mul/fma, ...)         4
+  half-rate  (compare, cndmask, min/max/med3, bfi/and_or/or3, shifts, cvt, every FP64 add/mul/fma, ...)         4
   f32 transcendental (rcp, rsq, sqrt)                                                                       8
   f64 transcendental                                                                                       16
 
@@ -25,7 +25,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COST = {"full": 2.0, "half": 4.0, "trans32": 8.0, "trans64": 16.0}
 MEASURED = {"full": 2.2, "half": 4.1, "trans32": 8.1, "trans64": 16.2}
 F32 = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32")
-FULL_OTHER = ("v_mov_b32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
+FULL_OTHER = ("v_mov_b32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
 T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32")
 T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
 F64CVT = ("v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64", "v_cvt_")

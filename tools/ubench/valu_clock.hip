@@ -38,7 +38,7 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
     for (int i = 0; i < iters; i++) {                                                                    \
       asm volatile(GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM)  \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
-                   : "v"(x), "v"(y));                                                                    \
+                   : "v"(x), "v"(y) : "vcc", "s20", "s21");                                              \
     }                                                                                                    \
     EPILOGUE                                                                                             \
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                         \
@@ -51,7 +51,7 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
     for (int i = 0; i < iters; i++) {                                                                    \
       asm volatile(GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM) GROUP(ASM)  \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)      \
-                   : "v"(x), "v"(y));                                                                    \
+                   : "v"(x), "v"(y) : "vcc", "s20", "s21");                                              \
     }                                                                                                    \
     EPILOGUE                                                                                             \
     out[blockIdx.x * 256 + threadIdx.x] = (float)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);                 \
@@ -68,6 +68,98 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
 #define A_ADD64(n) "v_add_f64 %" #n ", %" #n ", %8\n"
 #define A_FMA64(n) "v_fma_f64 %" #n ", %" #n ", %9, %8\n"
 #define A_RCP64(n) "v_rcp_f64 %" #n ", %" #n "\n"
+// round 3: the bit-field / three-operand integer forms the sphere screen is made of (is any of them full rate?)
+#define A_BITOP3(n) "v_bitop3_b32 %" #n ", %" #n ", %8, %9 bitop3:0x6c\n"
+#define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_ANDOR_INL(n) "v_and_or_b32 %" #n ", %" #n ", -16, 3\n"
+#define A_BFI(n) "v_bfi_b32 %" #n ", %8, %" #n ", %9\n"
+#define A_MED3F(n) "v_med3_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_MED3U(n) "v_med3_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_MIN3U(n) "v_min3_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_MINU(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define A_MAXF(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define A_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define A_OR3(n) "v_or3_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 4, %9\n"
+#define A_XAD(n) "v_xad_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_ADDABS(n) "v_add_f32_e64 %" #n ", |%" #n "|, %8\n"
+#define A_MULNEG(n) "v_mul_f32_e64 %" #n ", %" #n ", -%9\n"
+#define A_FMAMK(n) "v_fmamk_f32 %" #n ", %" #n ", 0x34000000, %8\n"
+#define A_CMPS(n) "v_cmp_ngt_f32_e64 s[20:21], |%" #n "|, %8\n"
+#define A_CMPV(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define A_CNDS(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\n"
+#define A_LSHL(n) "v_lshlrev_b32 %" #n ", 1, %" #n "\n"
+#define A_SQRT32(n) "v_sqrt_f32 %" #n ", %" #n "\n"
+#define A_MULLIT(n) "v_mul_f32 %" #n ", 0x7e800000, %" #n "\n"
+#define A_PKMUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_PKADD(n) "v_pk_add_f32 %" #n ", %" #n ", %8\n"
+#define A_SUBU(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define A_MADU24(n) "v_mad_u32_u24 %" #n ", %" #n ", 4, %9\n"
+#define A_MULU24(n) "v_mul_u32_u24 %" #n ", 16, %" #n "\n"
+#define A_MADI24(n) "v_mad_i32_i24 %" #n ", %" #n ", %8, %9\n"
+#define A_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %8, 28\n"
+#define A_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 2, 30\n"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_CVTF32U32(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define A_LDEXP(n) "v_ldexp_f32 %" #n ", %" #n ", %9\n"
+#define A_CNDVCC(n) "v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define A_FMA3(n) "v_fma_f32 %" #n ", %8, %9, %" #n "\n"
+#define A_FMAC(n) "v_fmac_f32 %" #n ", %8, %9\n"
+#define A_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 4, %9\n"
+#define A_ADDLSHL(n) "v_add_lshl_u32 %" #n ", %" #n ", %8, 2\n"
+#define A_LSHR(n) "v_lshrrev_b32 %" #n ", 2, %" #n "\n"
+#define A_ASHR(n) "v_ashrrev_i32 %" #n ", 31, %" #n "\n"
+#define A_MINI(n) "v_min_i32 %" #n ", %" #n ", %8\n"
+#define A_SUBF32SDWA(n) "v_add_f32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+#define A_MOVDPP(n) "v_mov_b32_dpp %" #n ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define A_MULF64(n) "v_mul_f64 %" #n ", %" #n ", %9\n"
+#define A_CVTF64F32(n) "v_cvt_f64_f32 %" #n ", %8\n"
+KERNEL32(mad_u32_u24, A_MADU24)
+KERNEL32(mul_u32_u24, A_MULU24)
+KERNEL32(mad_i32_i24, A_MADI24)
+KERNEL32(alignbit_b32, A_ALIGNBIT)
+KERNEL32(bfe_u32, A_BFE)
+KERNEL32(perm_b32, A_PERM)
+KERNEL32(cvt_f32_u32, A_CVTF32U32)
+KERNEL32(ldexp_f32, A_LDEXP)
+KERNEL32(cndmask_vcc, A_CNDVCC)
+KERNEL32(fma_f32_3src, A_FMA3)
+KERNEL32(fmac_f32, A_FMAC)
+KERNEL32(lshl_or_b32, A_LSHLOR)
+KERNEL32(add_lshl_u32, A_ADDLSHL)
+KERNEL32(lshrrev_b32, A_LSHR)
+KERNEL32(ashrrev_i32, A_ASHR)
+KERNEL32(min_i32, A_MINI)
+KERNEL32(add_f32_sdwa, A_SUBF32SDWA)
+KERNEL32(mov_b32_dpp, A_MOVDPP)
+KERNEL64(mul_f64, A_MULF64)
+KERNEL32(bitop3_b32, A_BITOP3)
+KERNEL32(and_or_b32, A_ANDOR)
+KERNEL32(and_or_inline, A_ANDOR_INL)
+KERNEL32(bfi_b32, A_BFI)
+KERNEL32(med3_f32, A_MED3F)
+KERNEL32(med3_u32, A_MED3U)
+KERNEL32(min3_u32, A_MIN3U)
+KERNEL32(min_u32, A_MINU)
+KERNEL32(max_f32, A_MAXF)
+KERNEL32(and_b32, A_AND)
+KERNEL32(or3_b32, A_OR3)
+KERNEL32(add3_u32, A_ADD3)
+KERNEL32(lshl_add_u32, A_LSHLADD)
+KERNEL32(xad_u32, A_XAD)
+KERNEL32(add_f32_abs, A_ADDABS)
+KERNEL32(mul_f32_neg, A_MULNEG)
+KERNEL32(fmamk_f32, A_FMAMK)
+KERNEL32(cmp_to_sgpr, A_CMPS)
+KERNEL32(cmp_to_vcc, A_CMPV)
+KERNEL32(cndmask_sgpr, A_CNDS)
+KERNEL32(lshlrev_b32, A_LSHL)
+KERNEL32(sqrt_f32, A_SQRT32)
+KERNEL32(mul_f32_lit, A_MULLIT)
+KERNEL64(pk_mul_f32, A_PKMUL)
+KERNEL64(pk_add_f32, A_PKADD)
+KERNEL32(sub_u32, A_SUBU)
 KERNEL32(add_f32, A_ADD32)
 KERNEL32(mul_f32, A_MUL32)
 KERNEL32(fma_f32, A_FMA32)
@@ -97,12 +189,23 @@ int main(int argc, char** argv) {
   std::vector<Stamp> hst((size_t)max_blocks * 4);
   Entry es[] = {E(add_f32, 1), E(mul_f32, 1), E(fma_f32, 1), E(min_f32, 1), E(mov_b32, 1), E(xor_b32, 1), E(rcp_f32, 1),
                 E(cmp_cnd_pair, 2), E(add_f64, 1), E(fma_f64, 1), E(rcp_f64, 1)};
+  Entry ext[] = {E(add_f32, 1), E(bitop3_b32, 1), E(and_or_b32, 1), E(and_or_inline, 1), E(bfi_b32, 1), E(med3_f32, 1), E(med3_u32, 1),
+                 E(min3_u32, 1), E(min_u32, 1), E(max_f32, 1), E(and_b32, 1), E(or3_b32, 1), E(add3_u32, 1), E(lshl_add_u32, 1),
+                 E(xad_u32, 1), E(add_f32_abs, 1), E(mul_f32_neg, 1), E(fmamk_f32, 1), E(cmp_to_sgpr, 1), E(cmp_to_vcc, 1),
+                 E(cndmask_sgpr, 1), E(lshlrev_b32, 1), E(sqrt_f32, 1), E(mul_f32_lit, 1), E(pk_mul_f32, 1), E(pk_add_f32, 1), E(sub_u32, 1)};
+  Entry ext2[] = {E(add_f32, 1), E(mad_u32_u24, 1), E(mul_u32_u24, 1), E(mad_i32_i24, 1), E(alignbit_b32, 1), E(bfe_u32, 1), E(perm_b32, 1),
+                  E(cvt_f32_u32, 1), E(ldexp_f32, 1), E(cndmask_vcc, 1), E(fma_f32_3src, 1), E(fmac_f32, 1), E(lshl_or_b32, 1),
+                  E(add_lshl_u32, 1), E(lshrrev_b32, 1), E(ashrrev_i32, 1), E(min_i32, 1), E(add_f32_sdwa, 1), E(mov_b32_dpp, 1), E(mul_f64, 1)};
+  const bool extended = argc > 2 && (argv[2][0] == 'x' || argv[2][0] == 'y');  // x, y: the two round-3 lists  // ./valu_clock 65536 x : the round-3 list, 8 and 4 waves per SIMD only
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
   printf("%s, %d CUs, clockRate %d kHz, %d iterations x 64 instructions per wave\n", prop.name, cus, prop.clockRate, iters);
-  for (auto& e : es) {
+  std::vector<Entry> run;
+  if (extended && argv[2][0] == 'y') run.assign(std::begin(ext2), std::end(ext2)); else if (extended) run.assign(std::begin(ext), std::end(ext)); else run.assign(std::begin(es), std::end(es));
+  for (auto& e : run) {
     for (int wps : {8, 5, 4, 2, 1}) {
+      if (extended && wps != 8 && wps != 4) continue;
       const int nb = cus * wps;  // wps blocks of 4 waves per CU: wps waves per SIMD IF the dispatcher spreads them evenly
       hipLaunchKernelGGL(e.fn, dim3(nb), dim3(256), 0, 0, out, st, 1.0f, 4096);  // warm
       CHECK(hipDeviceSynchronize());
