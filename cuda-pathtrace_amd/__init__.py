@@ -141,6 +141,7 @@ LAB_ABI = {
 FN_INV_SQRT_LITERAL, FN_INV_SQRT_FAST, FN_SQRT_LITERAL, FN_SQRT_FAST, FN_SIN, FN_COS, FN_UNIFORM = range(7)
 FN_ONEMINUS_LITERAL, FN_ONEMINUS_FAST, FN_ONEMINUS_F32, FN_ONEMINUS_F32_FLAG, FN_ZERO = 7, 8, 9, 10, 11
 FN_UNIFORM_LITERAL = 12
+FN_SIN_LITERAL, FN_COS_LITERAL = 13, 14
 
 lib = ctypes.CDLL(LIB_PATH)
 for _name, (_res, _args) in ABI.items():

@@ -36,6 +36,8 @@ __device__ __forceinline__ float eval_unary(int fn, float x) {
     }
     case PT_FN_ZERO: return 0.0f;
     case PT_FN_UNIFORM_LITERAL: return uniform_from_u32_literal(__float_as_uint(x));
+    case PT_FN_SIN_LITERAL: pt_sincos_literal(x, s, c); return s;
+    case PT_FN_COS_LITERAL: pt_sincos_literal(x, s, c); return c;
     default: return __builtin_nanf("");
   }
 }

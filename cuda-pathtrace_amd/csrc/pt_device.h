@@ -78,8 +78,11 @@ __device__ __forceinline__ uint32_t xorwow_next(Xorwow& s) {
   s.v1 = s.v2;
   s.v2 = s.v3;
   s.v3 = s.v4;
-  // (v4 ^ (v4 << 4)) ^ (t ^ (t << 1)): the same word from one shift (half rate), one add (t << 1 = t + t), one three-way xor
-  s.v4 = bitop3<0x96>(s.v4 ^ (s.v4 << 4), t, t + t);
+  // (v4 ^ (v4 << 4)) ^ (t ^ (t << 1)): the same word from one left shift (half rate; right shifts are full rate), one add
+  // (t << 1 = t + t; written as the instruction, the compiler turns the sum back into a shift) and one three-way xor
+  uint32_t t2;
+  asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
+  s.v4 = bitop3<0x96>(s.v4 ^ (s.v4 << 4), t, t2);
   s.d += 362437u;
   return s.v4 + s.d;
 }
@@ -147,7 +150,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
 }
 
 // ---- sin/cos on (0, 2*pi] (contract C4) ----------------------------------------------------
-__device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
+// The definition, as the oracle writes it (oracle/pt_oracle.c, pto_sincos): rintf, int conversion, compares and selects.
+__device__ __forceinline__ void pt_sincos_literal(float x, float& s, float& c) {
   float kf = rintf(x * 6.366197467e-01f);
   int k = (int)kf;
   float r = fmaf(-kf, 1.570796371e+00f, x);
@@ -168,6 +172,36 @@ __device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
   // quadrant signs: k&3 = 0:(s,c) 1:(c,-s) 2:(-s,-c) 3:(-c,s)
   s = (k & 2) ? -ss : ss;
   c = ((k + 1) & 2) ? -cc : cc;
+}
+// The same two floats for every |x| < 2^22 * pi/2 except x = -0 (tests/test_unary_exhaustive_gpu.py compares all of those bit
+// patterns; the path's argument is u * 2 * pi in (0, 2*pi]) from full-rate instructions only, bar one shift: the rounding to
+// the nearest quadrant is the magic-number addition (t + 1.5 * 2^23 rounds t to an integer, ties to even, exactly as rintf does,
+// and leaves k in the sum's low mantissa bits: no v_rndne_f32, no v_cvt_i32_f32), the quadrant's exchange and signs are bit
+// selections and sign flips (v_bitop3_b32) instead of three compares and four selects at half rate: 48 -> 28 issue cycles.
+__device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
+  const float t = x * 6.366197467e-01f;
+  const float y = t + 12582912.0f;
+  const float kf = y - 12582912.0f;
+  const uint32_t kb = __float_as_uint(y);  // 0x4B400000 + k: the low bits are k's (two's complement)
+  float r = fmaf(-kf, 1.570796371e+00f, x);
+  r = fmaf(-kf, -4.371138829e-08f, r);
+  r = fmaf(-kf, -1.715124510e-15f, r);
+  float r2 = r * r;
+  float ps = fmaf(r2, 2.755731884e-06f, -1.984127011e-04f);
+  ps = fmaf(ps, r2, 8.333333768e-03f);
+  ps = fmaf(ps, r2, -1.666666716e-01f);
+  float sr = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.755731998e-07f, 2.480158764e-05f);
+  pc = fmaf(pc, r2, -1.388888923e-03f);
+  pc = fmaf(pc, r2, 4.166666791e-02f);
+  float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const uint32_t odd = 0u - (kb & 1u);  // all ones in an odd quadrant: sine and cosine change places
+  const uint32_t ss = bitop3<0xE4>(__float_as_uint(cr), __float_as_uint(sr), odd);  // (a & c) | (b & ~c)
+  const uint32_t cc = bitop3<0xE4>(__float_as_uint(sr), __float_as_uint(cr), odd);
+  const uint32_t w = kb << 30;       // bit 31 = bit 1 of k: the sine's sign
+  const uint32_t w1 = w ^ (w + w);   // bit 31 = bit 1 ^ bit 0 of k = bit 1 of k + 1: the cosine's sign
+  s = __uint_as_float(bitop3<0x78>(ss, w, 0x80000000u));  // a ^ (b & c)
+  c = __uint_as_float(bitop3<0x78>(cc, w1, 0x80000000u));
 }
 
 // ---- luminance: src/pathtrace.cu:67-69 (double through the literals) -----------------------
@@ -251,7 +285,7 @@ __device__ __forceinline__ F3 cosine_weighted(F3 dir, float u_az, float u_el) {
   float ry = sqrtf(u_el);  // powf(u, 0.5f) := sqrtf(u), contract C3
   float oneminus = (float)sqrt(1.0 - (double)(ry * ry));
   float sn, cs;
-  pt_sincos(rx, sn, cs);
+  pt_sincos_literal(rx, sn, cs);  // the literal kernel keeps the definition
   F3 a = o1 * (cs * oneminus);
   F3 b = o2 * (sn * oneminus);
   F3 c = dir * ry;
@@ -534,8 +568,10 @@ __device__ __forceinline__ bool intersect_sphere_nb_oc(F3 off, float c, F3 d, co
   // denominator 2a > 0, monotonic rounding).  tNear > 0 <=> nb - sq > 0 (the quotient keeps the
   // sign; a positive quotient that would round to float zero is outside the checked range and
   // goes to the literal code), so only that one quotient is evaluated.
-  const double n_near = nb - sq;
-  const double num = (n_near > 0.0) ? n_near : nb + sq;
+  // = (n_near > 0.0) ? n_near : nb + sq with n_near = nb - sq: the difference is positive exactly when nb > sq, so the
+  // sign of sq is chosen first (one select on the high word) and ONE sum formed
+  const uint32_t sq_hi = (uint32_t)__double2hiint(sq);
+  const double num = nb + __hiloint2double((int)((nb > sq) ? (sq_hi ^ 0x80000000u) : sq_hi), __double2loint(sq));
   t = quotient_to_float_nb(num, rc, bad_here);
   const bool real = det >= 0.0f;
   bad = bad | (real & bad_here);  // a negative or non-finite disc under det >= 0 lands here too

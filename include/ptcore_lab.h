@@ -20,7 +20,7 @@ enum {
   PT_FN_INV_SQRT_FAST = 1,    /* the 7-instruction sequence the kernel uses for the same value   */
   PT_FN_SQRT_LITERAL = 2,     /* sqrtf(x)                                                        */
   PT_FN_SQRT_FAST = 3,        /* 5-instruction correctly rounded sqrt                             */
-  PT_FN_SIN = 4,              /* contract C4 sin on (0, 2*pi]                                     */
+  PT_FN_SIN = 4,              /* contract C4 sin on (0, 2*pi], the kernels' instruction sequence  */
   PT_FN_COS = 5,              /* contract C4 cos                                                  */
   PT_FN_UNIFORM = 6,          /* curand_uniform mapping of the argument's BIT PATTERN             */
   PT_FN_ONEMINUS_LITERAL = 7, /* (float)sqrt(1.0 - (double)(x*x)), pathtrace.cu:134               */
@@ -29,7 +29,9 @@ enum {
   PT_FN_ONEMINUS_F32_FLAG = 10, /* 1.0f where oneminus_f32_nb flags itself, else 0.0f                              */
   PT_FN_ZERO = 11,
   PT_FN_UNIFORM_LITERAL = 12, /* curand_uniform as multiply, then add (the kernels use the equivalent single fma) */
-  PT_FN_COUNT = 13
+  PT_FN_SIN_LITERAL = 13,     /* contract C4 as the oracle writes it (rintf, int conversion, selects); PT_FN_SIN/COS are the  */
+  PT_FN_COS_LITERAL = 14,     /* kernels' form of the same floats (magic-number rounding, bit selections)                     */
+  PT_FN_COUNT = 15
 };
 int pt_debug_unary_map(int fn, const float* d_in, float* d_out, size_t n);
 /* Compare fn_a and fn_b on the `count` consecutive float bit patterns starting at first_bits

@@ -42,6 +42,19 @@ def test_uniform_as_one_fma_equals_multiply_then_add_for_every_draw(lab, gpu):
     assert bad == 0, f"{bad} draws differ, e.g. 0x{example:08x}"
 
 
+def test_sincos_by_bit_selection_equals_the_definition(lab, gpu):
+    """Contract C4's sin/cos as the kernels evaluate it (magic-number rounding to the quadrant, v_bitop3 selections and sign
+    flips: pt_device.h, pt_sincos) against the definition as the oracle writes it (rintf, int conversion, compares, selects)
+    for EVERY float of magnitude below 4e6 -- far beyond the (0, 2*pi] the path uses -- except -0, where the sign of a zero
+    remainder differs."""
+    hi = int(np.float32(4.0e6).view(np.uint32))
+    for fast, literal in ((lab.FN_SIN, lab.FN_SIN_LITERAL), (lab.FN_COS, lab.FN_COS_LITERAL)):
+        bad, example = lab.unary_compare(fast, literal, 0, hi)
+        assert bad == 0, f"{bad} arguments differ, e.g. bits 0x{example:08x}"
+        bad, example = lab.unary_compare(fast, literal, 0x80000001, hi - 1)
+        assert bad == 0, f"{bad} negative arguments differ, e.g. bits 0x{example:08x}"
+
+
 def test_device_literals_match_cpu(lab, oracle, gpu):
     rng = np.random.default_rng(5)
     bits = np.concatenate([rng.integers(0x00800000, 0x7F800000, 1 << 22, dtype=np.uint32),

@@ -11,7 +11,7 @@ import re
 import sys
 
 FULL = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mov_b32",
-        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_accvgpr", "v_mov_b64")
+        "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_accvgpr", "v_mov_b64")
 T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32")
 T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
 

@@ -25,7 +25,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COST = {"full": 2.0, "half": 4.0, "trans32": 8.0, "trans64": 16.0}
 MEASURED = {"full": 2.2, "half": 4.1, "trans32": 8.1, "trans64": 16.2}
 F32 = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32")
-FULL_OTHER = ("v_mov_b32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
+FULL_OTHER = ("v_mov_b32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_bitop3_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
 T32 = ("v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32")
 T64 = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
 F64CVT = ("v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64", "v_cvt_")

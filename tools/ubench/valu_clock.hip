@@ -115,6 +115,14 @@ struct Stamp { unsigned long long cyc, w0, w1; unsigned hwid, xcc; };
 #define A_MOVDPP(n) "v_mov_b32_dpp %" #n ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 #define A_MULF64(n) "v_mul_f64 %" #n ", %" #n ", %9\n"
 #define A_CVTF64F32(n) "v_cvt_f64_f32 %" #n ", %8\n"
+// one compare feeding three selects (the shape of "flip the normal", "orthogonal vector", the sincos quadrant), through VCC and
+// through an SGPR pair; and selects alone on a VCC written once before the loop (cndmask_vcc above: 22.9 cycles each!)
+#define A_CMP3CND_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %9, vcc\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\nv_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define A_CMP3CND_SGPR(n) "v_cmp_lt_f32_e64 s[20:21], %" #n ", %8\nv_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\nv_cndmask_b32_e64 %" #n ", %" #n ", %8, s[20:21]\nv_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\n"
+#define A_CMP3XOR(n) "v_cmp_lt_f32_e64 s[20:21], %" #n ", %8\nv_cndmask_b32_e64 %" #n ", 0, %9, s[20:21]\nv_xor_b32 %" #n ", %" #n ", %8\nv_xor_b32 %" #n ", %" #n ", %9\n"
+KERNEL32(cmp_3cnd_vcc, A_CMP3CND_VCC)
+KERNEL32(cmp_3cnd_sgpr, A_CMP3CND_SGPR)
+KERNEL32(cmp_cnd_2xor, A_CMP3XOR)
 KERNEL32(mad_u32_u24, A_MADU24)
 KERNEL32(mul_u32_u24, A_MULU24)
 KERNEL32(mad_i32_i24, A_MADI24)
@@ -196,13 +204,14 @@ int main(int argc, char** argv) {
   Entry ext2[] = {E(add_f32, 1), E(mad_u32_u24, 1), E(mul_u32_u24, 1), E(mad_i32_i24, 1), E(alignbit_b32, 1), E(bfe_u32, 1), E(perm_b32, 1),
                   E(cvt_f32_u32, 1), E(ldexp_f32, 1), E(cndmask_vcc, 1), E(fma_f32_3src, 1), E(fmac_f32, 1), E(lshl_or_b32, 1),
                   E(add_lshl_u32, 1), E(lshrrev_b32, 1), E(ashrrev_i32, 1), E(min_i32, 1), E(add_f32_sdwa, 1), E(mov_b32_dpp, 1), E(mul_f64, 1)};
-  const bool extended = argc > 2 && (argv[2][0] == 'x' || argv[2][0] == 'y');  // x, y: the two round-3 lists  // ./valu_clock 65536 x : the round-3 list, 8 and 4 waves per SIMD only
+  Entry ext3[] = {E(add_f32, 1), E(cmp_3cnd_vcc, 4), E(cmp_3cnd_sgpr, 4), E(cmp_cnd_2xor, 4), E(cndmask_sgpr, 1), E(cndmask_vcc, 1), E(lshlrev_b32, 1), E(lshrrev_b32, 1)};
+  const bool extended = argc > 2 && (argv[2][0] == 'x' || argv[2][0] == 'y' || argv[2][0] == 'z');  // x, y: the two round-3 lists  // ./valu_clock 65536 x : the round-3 list, 8 and 4 waves per SIMD only
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
   printf("%s, %d CUs, clockRate %d kHz, %d iterations x 64 instructions per wave\n", prop.name, cus, prop.clockRate, iters);
   std::vector<Entry> run;
-  if (extended && argv[2][0] == 'y') run.assign(std::begin(ext2), std::end(ext2)); else if (extended) run.assign(std::begin(ext), std::end(ext)); else run.assign(std::begin(es), std::end(es));
+  if (extended && argv[2][0] == 'z') run.assign(std::begin(ext3), std::end(ext3)); else if (extended && argv[2][0] == 'y') run.assign(std::begin(ext2), std::end(ext2)); else if (extended) run.assign(std::begin(ext), std::end(ext)); else run.assign(std::begin(es), std::end(es));
   for (auto& e : run) {
     for (int wps : {8, 5, 4, 2, 1}) {
       if (extended && wps != 8 && wps != 4) continue;
