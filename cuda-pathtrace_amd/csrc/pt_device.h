@@ -28,9 +28,20 @@ template <int TT>
 __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
-// copysignf(mag, -sgn): (a & c) | (~b & ~c)
-__device__ __forceinline__ float copysign_neg_b3(float mag, float sgn) {
-  return __uint_as_float(bitop3<0xB1>(__float_as_uint(mag), __float_as_uint(sgn), 0x7FFFFFFFu));
+// A constant that must live in a VGPR.  ANY VALU instruction with an SGPR source operand issues at half rate on gfx950 -- even
+// v_add_f32 v, s, v (tools/ubench/valu_banks.hip, profiles/r03/valu_banks.txt) -- and the compiler keeps the non-inline constants
+// of VOP3 instructions in SGPRs.  The move is opaque to it.  Called ONCE per kernel (stage_scene: SceneLds::absmask) and handed
+// down: the unroller prices every inline-assembly statement highly, and one per sphere test stops the bounce loop from being
+// unrolled.  Inline constants (-16..64, 0.5, 1, 2, 4 and their negatives) cost nothing either way.
+template <uint32_t C>
+__device__ __forceinline__ uint32_t vgpr_const() {
+  uint32_t r;
+  asm("v_mov_b32 %0, %1" : "=v"(r) : "n"(C));
+  return r;
+}
+// copysignf(mag, -sgn): (a & c) | (~b & ~c); absmask = 0x7FFFFFFF, in a VGPR for the hot paths (SceneLds::absmask)
+__device__ __forceinline__ float copysign_neg_b3(float mag, float sgn, uint32_t absmask = 0x7FFFFFFFu) {
+  return __uint_as_float(bitop3<0xB1>(__float_as_uint(mag), __float_as_uint(sgn), absmask));
 }
 // copysignf(mag, sgn) (the library form compiles to the half-rate v_bfi_b32)
 __device__ __forceinline__ float copysign_b3(float mag, float sgn) {
@@ -178,7 +189,7 @@ __device__ __forceinline__ void pt_sincos_literal(float x, float& s, float& c) {
 // the nearest quadrant is the magic-number addition (t + 1.5 * 2^23 rounds t to an integer, ties to even, exactly as rintf does,
 // and leaves k in the sum's low mantissa bits: no v_rndne_f32, no v_cvt_i32_f32), the quadrant's exchange and signs are bit
 // selections and sign flips (v_bitop3_b32) instead of three compares and four selects at half rate: 48 -> 28 issue cycles.
-__device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
+__device__ __forceinline__ void pt_sincos(float x, float& s, float& c, uint32_t absmask = 0x7FFFFFFFu) {
   const float t = x * 6.366197467e-01f;
   const float y = t + 12582912.0f;
   const float kf = y - 12582912.0f;
@@ -200,8 +211,8 @@ __device__ __forceinline__ void pt_sincos(float x, float& s, float& c) {
   const uint32_t cc = bitop3<0xE4>(__float_as_uint(sr), __float_as_uint(cr), odd);
   const uint32_t w = kb << 30;       // bit 31 = bit 1 of k: the sine's sign
   const uint32_t w1 = w ^ (w + w);   // bit 31 = bit 1 ^ bit 0 of k = bit 1 of k + 1: the cosine's sign
-  s = __uint_as_float(bitop3<0x78>(ss, w, 0x80000000u));  // a ^ (b & c)
-  c = __uint_as_float(bitop3<0x78>(cc, w1, 0x80000000u));
+  s = __uint_as_float(bitop3<0xB4>(ss, w, absmask));  // a ^ (b & ~c): the sign bit of w flips ss (absmask in a VGPR: hot paths)
+  c = __uint_as_float(bitop3<0xB4>(cc, w1, absmask));
 }
 
 // ---- luminance: src/pathtrace.cu:67-69 (double through the literals) -----------------------
@@ -609,7 +620,7 @@ struct BounceGeom {
 // TAB: unit_tab = SceneLds::inv1, the LDS table for normalize_unit_nb (scenes that are not staged have none: the general sequence)
 template <bool FAST, bool TAB = false>
 __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 centre, float u_az, float u_el, bool& bad,
-                                                      const float* unit_tab = nullptr) {
+                                                      const float* unit_tab = nullptr, uint32_t absmask = 0x7FFFFFFFu) {
   BounceGeom out;
   F3 pos = o + d * t;
   F3 normal = pos - centre;
@@ -639,7 +650,7 @@ __device__ __forceinline__ BounceGeom bounce_geometry(F3 o, F3 d, float t, F3 ce
   // :131 u * 2.0f * 3.141592654f: doubling is exact, so the one product with 2 pi rounds the same real number
   float rx = FAST ? u_az * (2.0f * 3.141592654f) : u_az * 2.0f * 3.141592654f;
   float sn, cs;
-  pt_sincos(rx, sn, cs);
+  pt_sincos(rx, sn, cs, absmask);
   F3 a = o1 * (cs * oneminus);
   F3 b = o2 * (sn * oneminus);
   F3 c = dir * ry;

@@ -190,6 +190,7 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 struct ScreenState {
   uint32_t k1, k2;
   bool unsure;
+  uint32_t absmask;  // SceneLds::absmask
 };
 
 // Everything in the screen is kept at HALF scale -- h = dot(d, off) = b / 2, hh = h*h = bb / 4, a*c = 4ac / 4, ... --
@@ -242,7 +243,7 @@ __device__ __forceinline__ uint32_t screen_sphere_oc(F3 off, float c, int i, F3 
   // q = h + copysign(s, h) = |h| + s with h's sign (no cancellation); the roots (x 2a, halved: a * t) are -q and -num / q.
   // -q is formed directly (s with the sign of -h, minus h: the same float, zero signs included, since both terms share a sign),
   // so that its BITS are at hand for the unsigned minimum below without a negation of their own.
-  const float TA = copysign_neg_b3(s, h) - h;      // root -b - sign(b) s
+  const float TA = copysign_neg_b3(s, h, st.absmask) - h;  // root -b - sign(b) s
   const float TB = num * __builtin_amdgcn_rcpf(TA);  // root -b + sign(b) s = (4ac + (b*b - bb)) / -q
   // The reference returns the smaller root if both are positive, else the positive one, else a non-positive number that its
   // caller discards (pathtrace.cu:82-88,99).  For float bit patterns that is ONE unsigned minimum: positive floats order like
@@ -290,7 +291,7 @@ __device__ __forceinline__ bool intersect_scene_screened_keys(const SceneLds& sc
   const int ib = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1));  // index bits (wave-uniform)
   const uint32_t imask = (1u << ib) - 1u;
   const float margin = 1.0f + (__builtin_ldexpf(1.0f, ib - 22) + 7.6293945e-06f);  // 2^-(22-ib) + 2^-17
-  ScreenState st{0xFFFFFFFFu, 0xFFFFFFFFu, false};
+  ScreenState st{0xFFFFFFFFu, 0xFFFFFFFFu, false, sc.absmask};
   auto key_of = [&](const float4 g, int i) -> uint32_t {
     if constexpr (PRIMARY) {
       const float4 e = sc.eyeg[i];
@@ -456,7 +457,7 @@ __device__ __forceinline__ bool intersect_scene_screened_large(const SceneLds& s
     const float s = __builtin_amdgcn_sqrtf(h.dacc);
     const float e = fmaf(h.b, h.b, -h.bb);
     const float num = h.a4c + e;
-    const float TA = copysign_neg_b3(s, h.b) - h.b;  // -q, q = b + copysign(s, b) (screen_sphere_oc)
+    const float TA = copysign_neg_b3(s, h.b, sc.absmask) - h.b;  // -q, q = b + copysign(s, b) (screen_sphere_oc)
     const float TB = num * __builtin_amdgcn_rcpf(TA);
     // the smaller positive root = the unsigned minimum of the bit patterns; sign bit set / NaN bits (dacc < 0) if there is none
     const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
@@ -568,7 +569,7 @@ __device__ __forceinline__ void intersect_paths(const SceneLds& sc, int n, const
 #pragma unroll
   for (int p = 0; p < P; p++) {
     rc[p] = (!PRIMARY && !sc.lean) ? make_ray_const_unit(d[p], sc.rden1) : make_ray_const(d[p]);
-    st[p] = ScreenState{0xFFFFFFFFu, 0xFFFFFFFFu, false};
+    st[p] = ScreenState{0xFFFFFFFFu, 0xFFFFFFFFu, false, sc.absmask};
     hit[p] = false;
   }
   if (n <= 0) return;

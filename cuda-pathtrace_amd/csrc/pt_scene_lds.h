@@ -42,6 +42,7 @@ struct SceneLds {
   const GridLds* grid;  // variants 11, 12, 13 only
   void* pool;           // variant 13: the workgroup's pool area (pt_grid.h: per wave a test ring and the owners' result slots)
   uint32_t prim_mask;   // wave-uniform: the spheres the bounce-0 screen of this wave has to rank (pt_footprint.h); all ones = every sphere
+  uint32_t absmask;     // 0x7FFFFFFF in a VGPR (vgpr_const, pt_device.h): operand of the hot paths' v_bitop3_b32 sign transfers
 
   // geometry of sphere i, i wave-uniform
   __device__ __forceinline__ float4 geom_uniform(int i) const {
@@ -79,7 +80,7 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
   SceneLds s{lds, lds + n, lds + 2 * n, lds + 3 * n, tables ? reinterpret_cast<float*>(tab) : nullptr,
              tables ? reinterpret_cast<double*>(tab + kUnitTabSize / 4) : nullptr,
              tables ? reinterpret_cast<float*>(tab + kUnitTabSize / 4 + kUnitTabSize / 2) : nullptr, lds + 4 * n + kTablesF4,
-             spheres, lean, false, nullptr, nullptr, 0xFFFFFFFFu};
+             spheres, lean, false, nullptr, nullptr, 0xFFFFFFFFu, vgpr_const<0x7FFFFFFFu>()};
   const float qnan = __builtin_nanf("");
   if (tables) {
     for (int i = threadIdx.x; i < kUnitTabSize; i += blockDim.x)  // the literal expression of helper_math's normalize (contract C2)

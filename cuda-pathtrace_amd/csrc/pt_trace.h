@@ -31,7 +31,7 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
     // met an input outside its verified domain (never observed in the Cornell box)
     rng.bounce(n, u_az, u_el);
     bool bad = false;
-    BounceGeom bg = bounce_geometry<true, true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad, sc.inv1);
+    BounceGeom bg = bounce_geometry<true, true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad, sc.inv1, sc.absmask);
 #ifndef PT_TIMING_ONLY_NO_SHADE_REDO
     if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
 #endif
@@ -190,7 +190,7 @@ __device__ __forceinline__ void trace_paths(PathResult (&res)[P], const SceneLds
 #pragma unroll
     for (int p = 0; p < P; p++) {
       bad[p] = false;
-      bg[p] = bounce_geometry<true, true>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p], sc.inv1);
+      bg[p] = bounce_geometry<true, true>(o[p], d[p], t[p], centre[p], u_az[p], u_el[p], bad[p], sc.inv1, sc.absmask);
     }
     // stage 2: rare literal redo, then commit
 #pragma unroll
