@@ -2,6 +2,7 @@
 // Host code only; device code is in pt_kernel.hip.  No CPU fallback exists: every compute
 // entry point fails with PT_ENODEVICE / PT_EHIP when no gfx950 device is usable.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -127,9 +128,21 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
   if (n_spheres > PT_SCREEN_MAX_SPHERES)
     return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
-  // philox is counter-based: no skip-ahead, no speculation.  The four-lane kernel wins below five one-lane waves per
-  // SIMD, the one-lane kernel above (numbers at PT_SPLIT_MAX_WAVES_PER_SIMD)
-  if (r->opts.rng_mode == PT_RNG_PHILOX) return (r->spp >= 4 && r->philox_split) ? 8 : PT_DEFAULT_VARIANT;
+  // philox is counter-based: no skip-ahead, no speculation.  Frames whose samples are chunked (spp >= 512): the four-lane kernel
+  // wins below five one-lane waves per SIMD, the one-lane kernel above (numbers at PT_SPLIT_MAX_WAVES_PER_SIMD).  Shorter
+  // frames are whole rounds of waves to the one-lane kernel -- R resident per SIMD: five in the 5-bounce reference build, else
+  // four -- and it wins where its rounds are nearly full (512^2 = 4 waves per SIMD, 64 spp: 0.82 against 0.88 ms; config 5's
+  // shape with philox 0.096 against 0.105), the four-lane kernel where a round would be mostly empty (576^2: 1.14 against 1.32);
+  // from three rounds on the tail no longer matters (profiles/r03/philox_policy.txt, philox_low.txt).
+  if (r->opts.rng_mode == PT_RNG_PHILOX) {
+    if (r->spp < 4) return PT_DEFAULT_VARIANT;
+    if (r->spp >= 512) return r->philox_split ? 8 : PT_DEFAULT_VARIANT;
+    const bool ref5 = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 6, r->opts.layout == PT_LAYOUT_PLANAR) == 5;
+    const double resident = ref5 ? (double)PT_REF_MIN_WAVES_PHILOX : (double)PT_MIN_WAVES;
+    const double rounds = ceil(r->waves_per_simd / resident);
+    if (rounds >= 3.0) return PT_DEFAULT_VARIANT;
+    return r->waves_per_simd < 0.78 * rounds * resident ? 8 : PT_DEFAULT_VARIANT;
+  }
   // xorwow: splitting must amortise the generator skip-ahead and only pays on small tiles
   if (!(r->spec_ok && r->spp >= 8)) return PT_DEFAULT_VARIANT;
   if (pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0)

@@ -43,7 +43,7 @@ __device__ __forceinline__ void var_update(Var& w, float x, float n_new, float r
 __device__ __forceinline__ float var_value(const Var& w) { return w.n < 2.0f ? 0.0f : w.M2 * __builtin_amdgcn_rcpf(w.n - 1.0f); }
 
 // one sphere (pathtrace.cu:72-91), FP32 only: true = real roots exist; t = the root the reference returns
-__device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, const float4 g, float& disc) {
+__device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, const float4 g, float& disc, uint32_t absmask) {
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
   const float h = dot3(d, off);                                                      // b / 2
   // :76 in the reference's order: |off|^2 is rounded BEFORE r^2 is subtracted.  For the 1e5-radius wall spheres that
@@ -55,14 +55,14 @@ __device__ __forceinline__ float sphere_t(F3 o, F3 d, float a, float inv_a, cons
   const float c = (off.x * off.x + off.y * off.y + off.z * off.z) - g.w;
   disc = fmaf(h, h, -a * c);                                                         // det / 4
   const float s = __builtin_amdgcn_sqrtf(disc);                                      // NaN when there is no real root
-  const float q = h + copysign_b3(s, h);
-  const float t_big = -q * inv_a;                       // the root of larger magnitude
-  const float t_small = -c * __builtin_amdgcn_rcpf(q);  // the other one: their product is c / a
-  // The reference returns the smaller root if it is positive, else the larger (:82-88).  Origin inside the sphere
-  // (c < 0): opposite signs, that is the positive = larger one; outside: same sign, the smaller one (if it is
-  // negative so is the other and the caller rejects it).  One median with +-inf does both.
-  const float K = __uint_as_float(bitop3<0x6C>(__float_as_uint(c), 0xFF800000u, 0x80000000u));  // c < 0 ? +inf : -inf
-  return __builtin_amdgcn_fmed3f(t_big, t_small, K);
+  const float nq = copysign_neg_b3(s, h, absmask) - h;  // -(h + copysign(s, h)): no cancellation (absmask in a VGPR: pt_device.h)
+  const float t_big = nq * inv_a;                       // the root of larger magnitude
+  const float t_small = c * __builtin_amdgcn_rcpf(nq);  // the other one: their product is c / a
+  // The reference returns the smaller root if both are positive, else the positive one, else a non-positive number its caller
+  // rejects (:82-88,99): as bit patterns that is one unsigned minimum -- positive floats order like their bits, and a set sign
+  // bit (or a NaN: no real root) lies above all of them (pt_intersect.h, screen_sphere_oc).
+  const uint32_t tb = __float_as_uint(t_big), ts = __float_as_uint(t_small);
+  return __uint_as_float(tb < ts ? tb : ts);
 }
 
 // intersectScene (pathtrace.cu:93-107): nearest accepted t.  Up to 64 spheres are ranked as unsigned keys = the bits
@@ -83,9 +83,8 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
     uint32_t best = 0xFFFFFFFFu;
     auto rank = [&](const float4 g, int i) {
       float disc;
-      const float t = sphere_t(o, d, a, inv_a, g, disc);
-      const uint32_t key = (__float_as_uint(t) | (__float_as_uint(disc) & 0x80000000u));
-      best = min(best, (key & ~imask) | (uint32_t)i);
+      const float t = sphere_t(o, d, a, inv_a, g, disc, sc.absmask);
+      best = min(best, bitop3<0xBA>(__float_as_uint(t), imask, (uint32_t)i));  // (t & ~imask) | i; no root / negative t: sign bit or NaN bits
     };
     const uint32_t full = nn >= 32 ? 0xFFFFFFFFu : (1u << nn) - 1u;
     uint32_t m = __builtin_amdgcn_readfirstlane(mask) & full;
@@ -107,7 +106,7 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
       return ((best & ~imask) != 0u) & (best < 0x49742400u);  // 0 < t < 1e6 on the key (sign bit set = no candidate)
     }
     float disc;
-    const float t = sphere_t(o, d, a, inv_a, sc.geom_lane(idx), disc);
+    const float t = sphere_t(o, d, a, inv_a, sc.geom_lane(idx), disc, sc.absmask);
     t_hit = t;
     return (best < 0x7F800000u) & (disc >= 0.0f) & (t > 0.0f) & (t < 1000000.0f);  // :94,:99
   }
@@ -115,7 +114,7 @@ __device__ __forceinline__ bool nearest(const SceneLds& sc, int n, F3 o, F3 d, f
   int bi = -1;
   for (int i = 0; i < n; i++) {
     float disc;
-    const float t = sphere_t(o, d, a, inv_a, sc.geom_uniform(i), disc);
+    const float t = sphere_t(o, d, a, inv_a, sc.geom_uniform(i), disc, sc.absmask);
     if (disc >= 0.0f && t > 0.0f && t < best) {  // :77,:99 (NaN compares false)
       best = t;
       bi = i;

@@ -51,6 +51,9 @@
 #ifndef PT_REF_MIN_WAVES
 #define PT_REF_MIN_WAVES 5  // ... of the reference-configuration builds of variant 6 (<= 96 VGPRs)
 #endif
+#ifndef PT_REF_MIN_WAVES_PHILOX
+#define PT_REF_MIN_WAVES_PHILOX 5  // ... and of the 5-bounce philox build (the 8-bounce one keeps PT_MIN_WAVES)
+#endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the
 // 9-sphere scene with many).

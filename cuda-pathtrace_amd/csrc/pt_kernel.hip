@@ -24,10 +24,12 @@ constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POO
 
 // the reference-configuration builds of variant 6 with the XORWOW generator fit 96 registers (12 bytes of spills, in cold code:
 // WRITE_SIZE stays at the algorithmic bytes): five waves per SIMD instead of four (headline frame 50.12 -> 49.81 ms, three
-// alternating runs each, profiles/r03/README.md).  Not the philox builds: their spills are warm (WRITE_SIZE 143 -> 400 MB per
-// frame) and buy nothing (51.1 vs 51.4 ms); every other build keeps its cap as well.
+// alternating runs each, profiles/r03/README.md).  The philox builds spilled warm then (WRITE_SIZE 143 -> 400 MB per frame) and
+// gained nothing; after the bit-operation work of round 3 the 5-bounce build fits 96 registers with ONE spilled word (a reload
+// per sample) and gains 1.5 % (48.73 -> 47.98 ms, tools/philox_ab.py); the 8-bounce build (4 words) does not (0.0963 -> 0.0971 ms)
+// and keeps four waves, like every other build.
 template <int VAR, int REFB, int RNG>
-constexpr int kMinWavesR = (VAR == 6 && REFB != 0 && RNG == PT_RNG_XORWOW) ? PT_REF_MIN_WAVES : kMinWaves<VAR>;
+constexpr int kMinWavesR = (VAR == 6 && REFB != 0) ? (RNG == PT_RNG_XORWOW ? PT_REF_MIN_WAVES : (REFB == 5 ? PT_REF_MIN_WAVES_PHILOX : kMinWaves<VAR>)) : kMinWaves<VAR>;
 
 // builds that can chain a pixel's samples through several workgroups of one launch (sample chunking, below): the reference-
 // configuration builds of variant 6 and the pooled grid kernel

@@ -544,9 +544,12 @@ def test_automatic_variant_policy(pt, oracle, gpu):
     halfp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=512)
     assert halfp.kernel_info(9)["variant"] == 6
     halfp.destroy()
-    quarterp = pt.Renderer(1024, 1024, 8, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=256)
-    assert quarterp.kernel_info(9)["variant"] == 8
-    quarterp.destroy()
+    # philox, frames too short for sample chunking: the one-lane kernel where its rounds of five resident waves per SIMD are
+    # nearly full (four of five), the four-lane kernel where a round would be mostly empty; chunked frames: four lanes below five
+    for rows, spp, expect in ((256, 8, 6), (192, 8, 8), (320, 8, 6), (384, 8, 8), (256, 1024, 8), (320, 1024, 6)):
+        r = pt.Renderer(1024, 1024, spp, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=rows)
+        assert r.kernel_info(9)["variant"] == expect, (rows, spp)
+        r.destroy()
     few = pt.Renderer(256, 256, 2)  # too few samples to split
     assert few.kernel_info(9)["variant"] == 6
     few.destroy()
