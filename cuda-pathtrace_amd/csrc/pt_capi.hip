@@ -144,9 +144,22 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
     return r->waves_per_simd < 0.78 * rounds * resident ? 8 : PT_DEFAULT_VARIANT;
   }
   // xorwow: splitting must amortise the generator skip-ahead and only pays on small tiles
-  if (!(r->spec_ok && r->spp >= 8)) return PT_DEFAULT_VARIANT;
-  if (pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0)
-    return small_tile_variant(r->waves_per_simd);  // the reference configuration: every kernel has a build for it
+  if (!r->spec_ok) return PT_DEFAULT_VARIANT;
+  const bool ref = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0;
+  // (four to seven samples per pixel: only where one wave per SIMD would run alone -- 256^2 x 4 spp: 0.042 against 0.056 ms)
+  if (r->spp < 8) return (ref && r->spp >= 4 && r->waves_per_simd <= 1.25) ? 8 : PT_DEFAULT_VARIANT;
+  if (ref) {  // the reference configuration: every kernel has a build for it
+    int v = small_tile_variant(r->waves_per_simd);
+    // Frames too short for sample chunking, from 64 spp up (profiles/r03/short_frames_xorwow.txt): below 2.75 waves per SIMD the
+    // four-lane kernel beats the two-lane one (320^2 x 64 spp: 0.456 against 0.493 ms), and where the one-lane kernel's second
+    // round of five resident waves would be mostly empty the two-lane kernel beats it (576^2: 1.20 against 1.29)
+    if (r->spp < 512 && r->spp >= 64) {
+      const double resident = (double)PT_REF_MIN_WAVES, rounds = ceil(r->waves_per_simd / resident);
+      if (r->waves_per_simd < 2.75) v = 8;
+      else if (rounds == 2.0 && r->waves_per_simd < 0.56 * rounds * resident) v = 9;
+    }
+    return v;
+  }
   return r->small_tile ? 8 : PT_DEFAULT_VARIANT;
 }
 

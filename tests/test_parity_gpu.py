@@ -550,6 +550,12 @@ def test_automatic_variant_policy(pt, oracle, gpu):
         r = pt.Renderer(1024, 1024, spp, rng_mode=pt.RNG_PHILOX, row_begin=0, row_end=rows)
         assert r.kernel_info(9)["variant"] == expect, (rows, spp)
         r.destroy()
+    # xorwow frames too short for sample chunking (tools/short_frames.py): four lanes below 2.75 waves per SIMD from 64 spp up,
+    # two lanes where a second round of the one-lane kernel would be mostly empty, four lanes at 4 spp only when a wave would run alone
+    for size, spp, mb, expect in ((320, 64, 5, 8), (320, 16, 5, 9), (576, 64, 5, 9), (576, 16, 5, 6), (640, 64, 5, 6), (512, 4, 8, 6), (256, 4, 8, 8), (256, 4, 5, 8)):
+        r = pt.Renderer(size, size, spp, max_bounces=mb)
+        assert r.kernel_info(9)["variant"] == expect, (size, spp, mb)
+        r.destroy()
     few = pt.Renderer(256, 256, 2)  # too few samples to split
     assert few.kernel_info(9)["variant"] == 6
     few.destroy()
