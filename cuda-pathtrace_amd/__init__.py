@@ -108,6 +108,7 @@ ABI = {
     "pt_renderer_destroy": (ctypes.c_int, [_vp]),
     "pt_renderer_render": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _fp]),
     "pt_renderer_enqueue": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _vp]),
+    "pt_renderer_check": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
     "pt_renderer_set_frame": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "pt_renderer_reset_rng": (ctypes.c_int, [_vp]),
     "pt_renderer_get_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
@@ -363,6 +364,13 @@ class Renderer:
         _, b = _f32(basis, 12)
         _, e = _f32(eye, 3)
         check(lib.pt_renderer_enqueue(self.handle, d_out, d_spheres, n_spheres, b, e, stream))
+
+    def check(self, wait=True):
+        """Status of the frames enqueued so far (raises PtError(PT_EKERNEL) for a frame whose sample-chunk chain broke);
+        returns the number of frames render() has repaired in place."""
+        n = ctypes.c_uint32(0)
+        check(lib.pt_renderer_check(self.handle, 1 if wait else 0, ctypes.byref(n)))
+        return n.value
 
     def set_frame(self, frame):
         check(lib.pt_renderer_set_frame(self.handle, frame))

@@ -60,6 +60,8 @@ struct pt_renderer {
   uint32_t chunks13;       // ... variant 13 ...
   uint32_t chunks_split;   // ... and the split kernels (variants 8, 9)
   uint64_t chunk_wait_ticks;  // how long a chunk waits for its predecessor (wall-clock ticks of the device)
+  long chunk_wait_ms;         // ... the same in milliseconds (env PT_CHUNK_TIMEOUT_MS, default 4000)
+  uint32_t repaired;          // frames whose broken chunk chain pt_renderer_render repaired (pt_renderer_check reports it)
   uint32_t* d_err;         // device error word (PT_DEVERR_*), raised by a kernel that could not go on correctly
   uint32_t* h_err;         // pinned host copy, valid once ev_err has completed
   hipEvent_t ev_err;
@@ -161,6 +163,24 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
     return v;
   }
   return r->small_tile ? 8 : PT_DEFAULT_VARIANT;
+}
+
+// opts.chunks, or env PT_CHUNKS when that is 0: 0 = automatic, 1 = never, 2..PT_CHUNKS_MAX = that many (anything else: automatic)
+static int requested_chunks(int opt) {
+  int want = opt;
+  if (want == 0) {
+    const char* env = getenv("PT_CHUNKS");
+    if (env && *env) want = atoi(env);
+  }
+  return (want < 0 || want > PT_CHUNKS_MAX) ? 0 : want;
+}
+
+// A chunk may be at most max_samples long (the worst chained wait must stay far inside the wait limit): more chunks for very
+// long frames, none at all if even PT_CHUNKS_MAX are not enough.  Returns the chunk count to use, 0 = no chunking.
+static uint32_t fit_chunks(int want, int spp, int max_samples) {
+  while (want >= 2 && want < PT_CHUNKS_MAX && (spp + want - 1) / want > max_samples) want *= 2;
+  if (want < 2 || want > PT_CHUNKS_MAX || (spp + want - 1) / want > max_samples) return 0u;
+  return (uint32_t)want;
 }
 
 extern "C" {
@@ -306,6 +326,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->chunks13 = 0;
   r->chunks_split = 0;
   r->chunk_wait_ticks = 0;
+  r->chunk_wait_ms = 0;
+  r->repaired = 0;
   r->d_err = nullptr;
   r->h_err = nullptr;
   r->ev_err = nullptr;
@@ -335,14 +357,12 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   // pixel and at most 8 one-lane waves per SIMD slot-round.  opts.chunks / env PT_CHUNKS: 0 = this policy, 1 = never, n = n chunks.
   // The hand-over buffer (104 B per tile pixel) is allocated by the first launch that really chunks (chunk_buffer()).
   if (e == hipSuccess) {
-    int want = o.chunks;
-    if (want == 0) {
-      const char* env = getenv("PT_CHUNKS");
-      if (env && *env) want = atoi(env);
-    }
-    if (want < 0 || want > PT_CHUNKS_MAX) want = 0;
+    // opts.chunks / env PT_CHUNKS, one reading for all three kernel families: 0 = the policies below, 1 = never, n = n chunks
+    const int asked = requested_chunks(o.chunks);
     hipDeviceProp_t prop;
-    if (want == 0 && r->spp >= 512 && r->tile_pixels > 0 && hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
+    const bool have_prop = hipGetDeviceProperties(&prop, r->device) == hipSuccess;
+    int want = asked;
+    if (want == 0 && r->spp >= 512 && r->tile_pixels > 0 && have_prop) {
       const uint64_t slots = (uint64_t)prop.multiProcessorCount * 4u * 4u * 64u;  // pixels resident at 4 waves per SIMD
       // The whole frame: two chunks (one hand-over per pixel; 49.95 -> 49.48 ms, eight: 49.40).  Row tiles -- what a rank of a multi-GPU
       // run renders -- are one or two rounds of waves and gain more from more chunks (tools/chunk_tile.py, profiles/r03/README.md;
@@ -351,22 +371,17 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
       if ((uint64_t)r->tile_pixels <= 8u * slots)
         want = r->waves_per_simd > 8.5 ? PT_CHUNKS : (r->waves_per_simd > 3.25 ? PT_CHUNKS_TILE : PT_CHUNKS_SMALL_TILE);
     }
-    // a chunk short enough that the worst chained wait stays far inside the wait limit: more chunks for very long frames
-    while (want >= 2 && want < PT_CHUNKS_MAX && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want *= 2;
-    if (want >= 2 && (r->spp + want - 1) / want > PT_CHUNK_MAX_SAMPLES) want = 0;
-    r->chunks = want >= 2 ? (uint32_t)want : 0u;
+    r->chunks = fit_chunks(want, r->spp, PT_CHUNK_MAX_SAMPLES);
     // The pooled grid kernel (variant 13): 512-pixel workgroups, two resident per CU, 25 ms each at 1000 spheres x 256 spp --
     // a 1024^2 frame is FOUR rounds of them and its time is whatever the last round's stragglers make it (measured: 98 or 107 ms
     // from one frame to the next, profiles/r03/README.md).  Enough chunks for about thirty-two rounds, each at least 32 samples
     // long (closed / open at 256 spp, chunks 1: 98-109 / 38.4 ms, 2: 101.5 / 36.4, 4: 97.3 / 35.4, 8: 96.0 / 35.1, 16: 97.9 / 36.3).
+    // Its samples are a hundred times as long as the nine-sphere kernel's (about 0.1 ms per sample and workgroup at 1000
+    // spheres), so a chunk is capped at PT_CHUNK_MAX_SAMPLES_GRID samples: the worst chained wait -- all chunks of a block
+    // co-resident, chunk k waits k chunk durations -- stays a fraction of a second.
     {
-      int want13 = o.chunks;
-      if (want13 == 0) {
-        const char* env = getenv("PT_CHUNKS");
-        if (env && *env) want13 = atoi(env);
-      }
-      if (want13 < 0 || want13 > PT_CHUNKS_MAX) want13 = 0;
-      if (want13 == 0 && r->tile_pixels > 0 && hipGetDeviceProperties(&prop, r->device) == hipSuccess) {
+      int want13 = asked;
+      if (want13 == 0 && r->tile_pixels > 0 && have_prop) {
         const uint64_t resident = (uint64_t)prop.multiProcessorCount * 2u;  // workgroups
         const uint64_t groups = ((uint64_t)r->tile_pixels + 511u) / 512u;
         const uint64_t rounds = (groups + resident - 1) / resident;
@@ -374,29 +389,18 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
         if (want13 > 8) want13 = 8;
         while (want13 >= 2 && r->spp / want13 < 32) want13 /= 2;
       }
-      while (want13 >= 2 && want13 < PT_CHUNKS_MAX && (r->spp + want13 - 1) / want13 > PT_CHUNK_MAX_SAMPLES) want13 *= 2;
-      if (want13 >= 2 && (r->spp + want13 - 1) / want13 > PT_CHUNK_MAX_SAMPLES) want13 = 0;
-      r->chunks13 = want13 >= 2 ? (uint32_t)want13 : 0u;
+      r->chunks13 = fit_chunks(want13, r->spp, PT_CHUNK_MAX_SAMPLES_GRID);
     }
     // the split kernels (small tiles of the reference configuration: one or two rounds of waves by construction): four chunks
     // (numbers at small_tile_variant)
-    {
-      int ws = o.chunks;
-      if (ws == 0) {
-        const char* env = getenv("PT_CHUNKS");
-        if (env && *env) ws = atoi(env);
-      }
-      if (ws == 0 && r->spp >= 512) ws = PT_CHUNKS_SPLIT;
-      while (ws >= 2 && ws < PT_CHUNKS_MAX && (r->spp + ws - 1) / ws > PT_CHUNK_MAX_SAMPLES) ws *= 2;
-      if (ws < 2 || ws > PT_CHUNKS_MAX || (r->spp + ws - 1) / ws > PT_CHUNK_MAX_SAMPLES) ws = 0;
-      r->chunks_split = (uint32_t)ws;
-    }
+    r->chunks_split = fit_chunks(asked == 0 && r->spp >= 512 ? PT_CHUNKS_SPLIT : asked, r->spp, PT_CHUNK_MAX_SAMPLES);
     int khz = 0;  // s_memrealtime ticks per millisecond
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
     long wait_ms = 4000;
     if (const char* env = getenv("PT_CHUNK_TIMEOUT_MS")) { if (*env) wait_ms = atol(env); }
     if (wait_ms < 1) wait_ms = 1;
     r->chunk_wait_ticks = (uint64_t)khz * (uint64_t)wait_ms;
+    r->chunk_wait_ms = wait_ms;
 #if PT_BUILD_EXPERIMENTS
     if (const char* env = getenv("PT_LAB_DEBUG")) r->debug = (uint32_t)strtoul(env, nullptr, 0);
 #endif
@@ -466,22 +470,33 @@ static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {
   return true;
 }
 
-// The error word of an earlier chunked launch: PT_EKERNEL once, and no more chunking for this renderer.
-static int check_device_error(pt_renderer* r, bool wait) {
+// The error word of an earlier chunked launch, once it has arrived (wait: block until it has).  *err receives the word (0 = the
+// chain held) and is cleared on the device; a broken chain also switches chunking off for this renderer for good -- whatever
+// broke it may do so again.
+static int take_device_error(pt_renderer* r, bool wait, uint32_t* err) {
+  *err = 0u;
   if (!r->err_pending) return PT_OK;
   if (wait) PT_HIP(hipEventSynchronize(r->ev_err));
   else if (hipEventQuery(r->ev_err) != hipSuccess) { (void)hipGetLastError(); return PT_OK; }
   r->err_pending = false;
-  const uint32_t err = *r->h_err;
-  if (err == 0u) return PT_OK;
+  *err = *r->h_err;
+  if (*err == 0u) return PT_OK;
   *r->h_err = 0u;
-  (void)hipMemset(r->d_err, 0, sizeof(uint32_t));
-  r->chunks = 0;  // fall back to unchunked launches permanently: whatever broke the chain may do so again
+  PT_HIP(hipMemset(r->d_err, 0, sizeof(uint32_t)));
+  r->chunks = 0;
   r->chunks13 = 0;
   r->chunks_split = 0;
-  return pt_fail(PT_EKERNEL, "render: sample-chunk chain broken (device error word 0x%x): a workgroup waited %.0f ms for its "
-                             "predecessor in vain; that frame is invalid, chunking is now off for this renderer", err,
-                 (double)r->chunk_wait_ticks / 1e5);
+  return PT_OK;
+}
+
+// ... as a status: PT_EKERNEL for a frame that was enqueued and is incomplete (pt_renderer_render repairs its own instead)
+static int check_device_error(pt_renderer* r, bool wait) {
+  uint32_t err = 0u;
+  const int rc = take_device_error(r, wait, &err);
+  if (rc != PT_OK || err == 0u) return rc;
+  return pt_fail(PT_EKERNEL, "render: sample-chunk chain broken (device error word 0x%x): a workgroup waited %ld ms for its "
+                             "predecessor in vain; that frame is incomplete (the pixel blocks concerned were left untouched, their "
+                             "generator state included), chunking is now off for this renderer", err, r->chunk_wait_ms);
 }
 
 static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
@@ -523,6 +538,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->err_word = r->d_err;
   a->chunk_wait_ticks = r->chunk_wait_ticks;
   a->debug = r->debug;
+  a->repair = 0u;
   return PT_OK;
 }
 
@@ -608,8 +624,32 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
   r->frame++;
   float ms = 0.0f;
   PT_HIP(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
+  // A synchronous frame whose chunk chain broke is completed HERE: the chunked launch left every pixel block either complete
+  // or untouched, generator state included (pt_kernel.hip, chunk_wait), so one unchunked launch over the untouched blocks
+  // makes the frame -- and the state the next frame starts from -- exactly what an unbroken launch would have left.
+  uint32_t err = 0u;
+  rc = take_device_error(r, true, &err);
+  if (rc != PT_OK) return rc;
+  if (err != 0u) {
+    a.repair = a.chunks;  // the count a complete block's flag holds
+    a.chunks = 0u;
+    PT_HIP(hipEventRecord(r->ev_start, nullptr));
+    PT_HIP(launch(r, a, nullptr));
+    PT_HIP(hipEventRecord(r->ev_stop, nullptr));
+    PT_HIP(hipEventSynchronize(r->ev_stop));
+    float ms2 = 0.0f;
+    PT_HIP(hipEventElapsedTime(&ms2, r->ev_start, r->ev_stop));
+    ms += ms2;
+    r->repaired++;
+  }
   if (ms_out) *ms_out = ms;
-  return check_device_error(r, true);  // a synchronous frame whose chain broke is an error of THIS call
+  return PT_OK;
+}
+
+int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames) {
+  if (!r) return pt_fail(PT_EINVAL, "pt_renderer_check: renderer is NULL");
+  if (repaired_frames) *repaired_frames = r->repaired;
+  return check_device_error(r, wait != 0);
 }
 
 int pt_renderer_set_frame(pt_renderer* r, uint32_t frame) {

@@ -116,6 +116,8 @@ struct PixelKernelArgs {
   uint64_t chunk_wait_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) a chunk waits for its predecessor before it gives up
   uint32_t debug;              // lab library only (PT_DEBUG_*): deliberate faults for the failure-path tests
   uint32_t prio;               // 1: one-lane-per-pixel waves set their issue priority by progress (filled in by the launcher)
+  uint32_t repair;             // != 0: repair launch after a broken chunk chain -- unchunked, and pixel blocks whose chunk_flag equals
+                               // this value (= the chunk count of the broken launch: complete) are skipped
 };
 // words handed from one chunk of a pixel block to the next: 10 sums, 2 counts (colour; the three first-hit accumulators share
 // one), 4 x {mean, M2}, and the 6 generator words (xorwow only; philox needs none)
@@ -133,7 +135,12 @@ struct PixelKernelArgs {
 // A chunk may only be as long as keeps the worst chained wait (all chunks of a block co-resident: chunk k waits k chunk
 // durations) far inside the wait limit: at most this many samples per chunk (about 50 ms of kernel time on an MI355X)
 #define PT_CHUNK_MAX_SAMPLES 4096
-#define PT_DEVERR_CHUNK_CHAIN 1u  // a chunk's predecessor never signalled: the frame is invalid
+// ... of the pooled grid kernel (variant 13), whose samples are a hundred times as long (about 0.1 ms per sample and 512-pixel
+// workgroup at 1000 spheres, three times that at 2048 spheres and 8 bounces): 16 co-resident chunks of 256 samples stay
+// near a second, a quarter of the default wait limit
+#define PT_CHUNK_MAX_SAMPLES_GRID 256
+#define PT_DEVERR_CHUNK_CHAIN 1u  // a chunk's predecessor never signalled: the frame is incomplete
+#define PT_CHUNK_FAILED 0x80000000u  // chunk_flag bit: the hand-over chain of this pixel block is broken (pt_kernel.hip, chunk_wait)
 #define PT_DEBUG_DROP_CHUNK_FLAG 1u  // pixel block 0, chunk 0 does not publish its flag (tests/test_chunk_chain_gpu.py)
 
 #ifndef PT_BUILD_EXPERIMENTS

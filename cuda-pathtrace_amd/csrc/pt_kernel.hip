@@ -36,6 +36,53 @@ constexpr int kMinWavesR = (VAR == 6 && REFB != 0) ? (RNG == PT_RNG_XORWOW ? PT_
 template <int VAR, int REFB>
 constexpr bool kChunkable = (VAR == 6 && REFB != 0) || VAR == 13;
 
+// ---- the hand-over chain of sample chunking (what it is for: pixel_kernel below) ------------------------------------------
+// chunk_flag[block]: bits 0-30 = chunks of the pixel block that have completed, bit 31 (PT_CHUNK_FAILED) = the chain is broken.
+// Wait for the predecessor of chunk `chunk`.  The wait is bounded in TIME (s_memrealtime) and giving up is an ERROR the host
+// sees (device error word -> PT_EKERNEL or a repair launch, pt_capi.hip), never a silent frame.  A workgroup that gives up, or
+// finds the chain already broken, marks the chain broken and leaves WITHOUT touching the frame, the hand-over buffer or the
+// generator state -- so do all its successors (they can only ever see the mark: the count stops below them), the last chunk
+// included, and the last chunk is the only one that writes the frame and the generator state.  Hence after a launch every
+// pixel block is either complete (count == chunks: frame and state exactly the reference's) or untouched (frame and state as
+// before the launch), which is what lets the host render the untouched blocks again, unchunked (a.repair).
+// Returns true (workgroup-uniform) when the caller has to leave.
+__device__ __forceinline__ bool chunk_wait(const PixelKernelArgs& a, uint32_t block_id, uint32_t chunk) {
+  __shared__ uint32_t s_pred;
+  if (threadIdx.x == 0) {
+    const uint64_t t0 = wall_clock64();
+    uint32_t spins = 0, f;
+    for (;;) {
+      f = __hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if ((f & PT_CHUNK_FAILED) != 0u || f >= chunk) break;
+      __builtin_amdgcn_s_sleep(32);
+      if ((++spins & 255u) == 0u && wall_clock64() - t0 > a.chunk_wait_ticks) {
+        f = PT_CHUNK_FAILED;
+        break;
+      }
+    }
+    if ((f & PT_CHUNK_FAILED) != 0u) {
+      if (a.err_word) atomicOr(a.err_word, PT_DEVERR_CHUNK_CHAIN);
+      __hip_atomic_fetch_or(a.chunk_flag + block_id, PT_CHUNK_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_pred = f;
+  }
+  __syncthreads();
+  return (s_pred & PT_CHUNK_FAILED) != 0u;
+}
+
+// chunk `chunk` of the block is complete: everything it stored is visible device-wide before the count says so.  The count
+// only grows and never clears the failure mark (a predecessor that was merely slow may finish after its successor gave up).
+__device__ __forceinline__ void chunk_publish(const PixelKernelArgs& a, uint32_t block_id, uint32_t chunk) {
+  __syncthreads();  // every wave's stores are issued ...
+  if (threadIdx.x == 0) {
+    __threadfence();  // ... and visible device-wide before the flag says so
+#if PT_BUILD_EXPERIMENTS  // lab library: a deliberately broken chain for the failure-path tests
+    if ((a.debug & PT_DEBUG_DROP_CHUNK_FLAG) && block_id == 0u && chunk == 0u) return;
+#endif
+    __hip_atomic_fetch_max(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
 __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
   constexpr bool REF = REFB != 0;
@@ -43,6 +90,11 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   if constexpr (REF) {
     a.n_spheres = 9;
     a.max_bounces = REFB;
+  }
+  if constexpr (CHUNKS) {
+    // repair launch (pt_capi.hip, after a chunked launch whose chain broke): unchunked, and only for the pixel blocks that
+    // launch left untouched -- the ones it completed are not rendered a second time
+    if (a.repair != 0u && __hip_atomic_load(a.chunk_flag + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.repair) return;
   }
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<VAR == 3>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
@@ -110,21 +162,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       i_begin = (int)chunk * per;
       i_end = i_begin + per < a.spp ? i_begin + per : a.spp;
       if (chunk > 0u) {
-        if (threadIdx.x == 0) {  // wait for the previous chunk of this pixel block
-          // The wait is bounded in TIME (s_memrealtime), and giving up is an ERROR the host reports (PT_EKERNEL), never a
-          // silent frame: the waiter raises the renderer's device error word, goes on with whatever the hand-over buffer
-          // holds and still publishes its own flag, so that its successors do not each wait out the limit as well.
-          const uint64_t t0 = wall_clock64();
-          uint32_t spins = 0;
-          while (__hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-            __builtin_amdgcn_s_sleep(32);
-            if ((++spins & 255u) == 0u && wall_clock64() - t0 > a.chunk_wait_ticks) {
-              if (a.err_word) atomicOr(a.err_word, PT_DEVERR_CHUNK_CHAIN);
-              break;
-            }
-          }
-        }
-        __syncthreads();
+        if (chunk_wait(a, block_id, chunk)) return;  // the chain of this pixel block is broken: nothing of the block is written
         if (active) {
           auto ld = [&](int w) { return __hip_atomic_load(a.chunk_state + (size_t)w * a.tile_pixels + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
           auto ldf = [&](int w) { return __uint_as_float(ld(w)); };
@@ -373,14 +411,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
           st(20, rng.st.d); st(21, rng.st.v0); st(22, rng.st.v1); st(23, rng.st.v2); st(24, rng.st.v3); st(25, rng.st.v4);
         }
       }
-      __syncthreads();  // every wave's stores are issued ...
-      if (threadIdx.x == 0) {
-        __threadfence();  // ... and visible device-wide before the flag says so
-#if PT_BUILD_EXPERIMENTS  // lab library: a deliberately broken chain for the failure-path test
-        if (!((a.debug & PT_DEBUG_DROP_CHUNK_FLAG) && block_id == 0u && chunk == 0u))
-#endif
-        __hip_atomic_store(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      chunk_publish(a, block_id, chunk);
       return;
     }
   }
@@ -433,6 +464,9 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       s[5] = rng.st.v4;
     }
   }
+  if constexpr (CHUNKS) {
+    if (n_chunks > 1u) chunk_publish(a, block_id, chunk);  // count == chunks: this block's frame and generator state are complete
+  }
 }
 
 // ---- variant 8: four lanes per pixel (small tiles) ----------------------------------------------
@@ -465,6 +499,9 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     a.max_bounces = REFB;
   }
   constexpr int kOwn = 4 / kSplit;  // features accumulated by one lane
+  if constexpr (REF) {  // repair launch: only the pixel blocks a broken chunked launch left untouched (pixel_kernel)
+    if (a.repair != 0u && __hip_atomic_load(a.chunk_flag + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.repair) return;
+  }
   extern __shared__ float4 lds_scene[];
   SceneLds sc = stage_scene<false>(a.spheres, a.n_spheres, lds_scene, LEAN, mk3(a.eye[0], a.eye[1], a.eye[2]), a.spp);
   sc.small_only = !LEAN && (kSplit == 4 || REF);  // variant 8 has a lean build for larger scenes, variant 9 has not (its REF builds see 9 spheres)
@@ -555,18 +592,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
       i_begin = (int)chunk * per < a.spp ? (int)chunk * per : a.spp;
       i_end = i_begin + per < a.spp ? i_begin + per : a.spp;
       if (chunk > 0u) {
-        if (threadIdx.x == 0) {  // wait for the previous chunk of this block: bounded in time, giving up is an error (pixel_kernel)
-          const uint64_t t0 = wall_clock64();
-          uint32_t spins = 0;
-          while (__hip_atomic_load(a.chunk_flag + block_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-            __builtin_amdgcn_s_sleep(32);
-            if ((++spins & 255u) == 0u && wall_clock64() - t0 > a.chunk_wait_ticks) {
-              if (a.err_word) atomicOr(a.err_word, PT_DEVERR_CHUNK_CHAIN);
-              break;
-            }
-          }
-        }
-        __syncthreads();
+        if (chunk_wait(a, block_id, chunk)) return;  // broken chain: nothing of the block is written (pixel_kernel)
         if (active) {
           auto ld = [&](int w) { return __hip_atomic_load(a.chunk_state + (size_t)w * a.tile_pixels + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
           auto ldf = [&](int w) { return __uint_as_float(ld(w)); };
@@ -751,11 +777,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
           }
         }
       }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_store(a.chunk_flag + block_id, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      chunk_publish(a, block_id, chunk);
       return;
     }
   }
@@ -785,6 +807,9 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
         p[3] = final_state.v2; p[4] = final_state.v3; p[5] = final_state.v4;
       }
     }
+  }
+  if constexpr (CHUNKS) {
+    if (n_chunks > 1u) chunk_publish(a, block_id, chunk);  // count == chunks: this block is complete
   }
 }
 
@@ -949,7 +974,8 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 // does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
   return (((variant == 6 || variant == 8 || variant == 9) && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar)) || variant == 13) && chunks > 1u &&
-         chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks && (spp + (int)chunks - 1) / (int)chunks <= PT_CHUNK_MAX_SAMPLES;
+         chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks &&
+         (spp + (int)chunks - 1) / (int)chunks <= (variant == 13 ? PT_CHUNK_MAX_SAMPLES_GRID : PT_CHUNK_MAX_SAMPLES);
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
@@ -974,7 +1000,8 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   const unsigned block = (unsigned)pt_kernel_block_threads(variant);
   unsigned grid = (unsigned)((lanes + block - 1) / block);
   // sample chunking: only the reference-configuration builds of variant 6 and variant 13 hand a pixel's state from workgroup to workgroup
-  const bool chunked = pt_kernel_chunked(variant, a.n_spheres, a.max_bounces, a.planar != 0u, a.spp, a.chunks) && a.chunk_state && a.chunk_flag;
+  const bool chunked = a.repair == 0u && pt_kernel_chunked(variant, a.n_spheres, a.max_bounces, a.planar != 0u, a.spp, a.chunks) && a.chunk_state && a.chunk_flag;
+  if (a.repair != 0u && !a.chunk_flag) return hipErrorInvalidValue;  // a repair launch reads the flags its chunked predecessor left
   b.chunks = chunked ? a.chunks : 0u;
   if (chunked) {
     hipError_t e = hipMemsetAsync(a.chunk_flag, 0, (size_t)grid * sizeof(uint32_t), stream);

@@ -305,6 +305,8 @@ void worker_frame(pt_mgpu* m, pt_mgpu::Rank& rk) {
     }
     std::this_thread::sleep_for(std::chrono::microseconds(20));  // a frame is >= milliseconds; do not burn a core per rank
   }
+  // the stream has drained: a frame whose sample-chunk chain broke belongs to THIS call, not to the next one (or to nobody)
+  if (count) note_pt(pt_renderer_check(rk.renderer, 1, nullptr));
   if (timed && first_rc == PT_OK) note_hip(hipEventElapsedTime(&rk.kernel_ms, rk.ev0, rk.ev1), "hipEventElapsedTime");
   rk.rc = first_rc;
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 enum {
   PT_OK = 0,
@@ -44,8 +44,11 @@ enum {
   PT_ELIMIT = -5,    /* scene does not fit the kernel's LDS staging budget   */
   PT_ECOMM = -6,     /* RCCL could not be loaded or a collective call failed (multi-GPU) */
   PT_ETIMEOUT = -7,  /* a multi-GPU frame did not complete in time; the exchange was aborted */
-  PT_EKERNEL = -8    /* the kernel itself reported a failure (sample-chunk chain broken): the frame it wrote is */
-                     /*   NOT valid; the renderer has switched sample chunking off and later frames are good   */
+  PT_EKERNEL = -8    /* the kernel itself reported a failure (sample-chunk chain broken) for a frame that was  */
+                     /*   ENQUEUED: that frame is incomplete -- the pixel blocks concerned were left untouched, */
+                     /*   their generator state included (re-seed with pt_renderer_reset_rng / _set_rng_state   */
+                     /*   to rejoin the reference's stream); sample chunking is off from then on.  A frame      */
+                     /*   rendered with pt_renderer_render is completed by the call itself and returns PT_OK.   */
 };
 
 /* struct Sphere, include/Scene.h:7-14 -- same 40-byte layout, so a reference
@@ -150,6 +153,13 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
  * separate renderers. */
 int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
                         const float basis[12], const float eye[3], void* hip_stream);
+
+/* Status of the frames enqueued so far (wait != 0: block until the last one's status word has arrived): PT_OK, or
+ * PT_EKERNEL once for a frame whose sample-chunk chain broke (see PT_EKERNEL; the next pt_renderer_enqueue /
+ * pt_renderer_render on the renderer would report it otherwise).  Call it after synchronising on the stream and
+ * before pt_renderer_destroy, which reports nothing.  *repaired_frames (may be NULL) receives the number of frames
+ * whose broken chain pt_renderer_render has repaired in place since the renderer was created (normally 0). */
+int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames);
 
 /* Frame counter used by the philox key; incremented by every render/enqueue. */
 int pt_renderer_set_frame(pt_renderer* r, uint32_t frame);

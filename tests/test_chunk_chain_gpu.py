@@ -1,5 +1,6 @@
-"""Sample chunking must fail LOUDLY: a workgroup whose predecessor never signals raises the renderer's device error word,
-the call returns PT_EKERNEL (never PT_OK with a wrong frame), and the renderer goes on unchunked -- bit-exact again.
+"""Sample chunking must never produce a silently wrong frame: a workgroup whose predecessor never signals raises the renderer's
+device error word and leaves its pixel block untouched.  Render() then completes the frame itself (repair launch), an enqueued
+frame is reported as PT_EKERNEL; either way the renderer goes on unchunked, bit-exact.
 The broken chain is provoked in the lab library (PT_LAB_DEBUG=1: pixel block 0, chunk 0 does not publish its flag)."""
 import os
 
@@ -100,40 +101,87 @@ def test_split_kernels_chunks(pt, gpu, oracle, rng, variant):
             r.destroy()
 
 
-def test_broken_chunk_chain_is_an_error_not_a_frame(lab, gpu, oracle):
-    w, h, spp = 64, 16, 640
-    basis = lab.camera_basis(width=w, height=h)
-    ref = oracle.render(w, h, spp, spheres=lab.scene_cornell(), basis=basis)
-    d_scene, n = lab.upload_scene(lab.scene_cornell())
-    d_out = lab.DeviceBuffer(w * h * 56)
+def _lab_renderers(lab, specs, timeout_ms=150):
+    """Renderers of the lab library created with the chunk-flag fault switched on (PT_LAB_DEBUG=1: pixel block 0, chunk 0 never
+    publishes its flag) and a short wait limit."""
     old = {k: os.environ.get(k) for k in ("PT_LAB_DEBUG", "PT_CHUNK_TIMEOUT_MS")}
     os.environ["PT_LAB_DEBUG"] = "1"
-    os.environ["PT_CHUNK_TIMEOUT_MS"] = "150"
+    os.environ["PT_CHUNK_TIMEOUT_MS"] = str(timeout_ms)
     try:
-        r = lab.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=4)   # synchronous Render(): the error belongs to this call
-        r2 = lab.Renderer(w, h, spp, variant=6, persist_rng=False, chunks=4)  # enqueue: reported by the next call on the renderer
+        return [lab.Renderer(*a, **k) for a, k in specs]
     finally:
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert r.kernel_info(n)["grid_blocks"] == 4 * ((w * h + 255) // 256)
+
+
+@pytest.mark.parametrize("variant", [6, 9, 13])
+def test_broken_chunk_chain_is_repaired_by_render(lab, gpu, oracle, variant):
+    """Synchronous Render(): the chunked launch leaves every pixel block complete or untouched (generator state included), the
+    call renders the untouched ones again unchunked, and frame AND persisted generator state are the oracle's -- with the
+    reference's default persist_rng, over two frames (the next frame must not continue a corrupted stream)."""
+    if variant == 13:
+        w, h, spp, chunks = 64, 24, 64, 4
+        scene = lab.scene_random(200, seed=5, with_walls=True)
+    else:
+        w, h, spp, chunks = 64, 16, 640, 4
+        scene = lab.scene_cornell()
+    basis = lab.camera_basis(width=w, height=h)
+    d_scene, n = lab.upload_scene(scene)
+    d_out = lab.DeviceBuffer(w * h * 56)
+    (r,) = _lab_renderers(lab, [((w, h, spp), dict(variant=variant, chunks=chunks))])
+    lanes = {6: 1, 9: 2, 13: 1}[variant]
+    block = 512 if variant == 13 else 256
+    assert r.kernel_info(n)["grid_blocks"] == chunks * ((w * h * lanes + block - 1) // block)
+    st = oracle.setup_random(w, h)
+    for frame in range(2):
+        d_out.upload(np.full((h, w, 14), -7.0, dtype=np.float32))
+        r.render(d_out.ptr, d_scene.ptr, n, basis)  # frame 0: chain broken and repaired; frame 1: unchunked
+        ref = oracle.render(w, h, spp, spheres=scene, basis=basis, rng_state=st)
+        assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref)), f"frame {frame}"
+        assert np.array_equal(r.get_rng_state(), st), f"generator state after frame {frame}"
+        assert r.check() == 1  # one repaired frame, nothing pending
+        # the renderer has stopped chunking: one workgroup per pixel block
+        assert r.kernel_info(n)["grid_blocks"] == (w * h * lanes + block - 1) // block
+    r.destroy()
+
+
+def test_broken_chunk_chain_of_an_enqueued_frame_is_an_error(lab, gpu, oracle):
+    """pt_renderer_enqueue cannot repair (nobody waits): the frame is incomplete and pt_renderer_check -- or the next call on the
+    renderer -- says so once; the pixel blocks concerned were left untouched, their generator state included, every other block
+    is the oracle's; after re-seeding, the renderer (now unchunked) is bit-exact again."""
+    w, h, spp = 64, 16, 640
+    basis = lab.camera_basis(width=w, height=h)
+    ref = oracle.render(w, h, spp, spheres=lab.scene_cornell(), basis=basis)
+    d_scene, n = lab.upload_scene(lab.scene_cornell())
+    d_out = lab.DeviceBuffer(w * h * 56)
+    r, r2 = _lab_renderers(lab, [((w, h, spp), dict(variant=6, chunks=4)), ((w, h, spp), dict(variant=6, chunks=4))])
+    fresh = r.get_rng_state()
+    d_out.upload(np.full((h, w, 14), -7.0, dtype=np.float32))
+    r.enqueue(d_out.ptr, d_scene.ptr, n, basis)
+    lab.check(lab.lib.pt_device_synchronize())
     with pytest.raises(lab.PtError) as e:
-        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        r.check()
     assert e.value.code == PT_EKERNEL and "chunk" in str(e.value)
-    # the renderer has stopped chunking: one workgroup per pixel block, and the frame is the oracle's again
-    assert r.kernel_info(n)["grid_blocks"] == (w * h + 255) // 256
-    r.render(d_out.ptr, d_scene.ptr, n, basis)
+    assert r.check() == 0  # reported once
+    got = d_out.download(np.float32, (h, w, 14)).reshape(-1, 14)
+    state = r.get_rng_state()
+    refp = ref.reshape(-1, 14)
+    assert np.all(got[:256] == -7.0) and np.array_equal(state[:256], fresh[:256])  # pixel block 0: untouched
+    assert np.array_equal(_bits(got[256:]), _bits(refp[256:]))                     # the others: complete
+    r.reset_rng()
+    r.enqueue(d_out.ptr, d_scene.ptr, n, basis)  # unchunked from here on
+    lab.check(lab.lib.pt_device_synchronize())
+    assert r.check() == 0
     assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref))
     r.destroy()
 
+    # without pt_renderer_check the next call on the renderer reports it
     r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)
     lab.check(lab.lib.pt_device_synchronize())
     with pytest.raises(lab.PtError) as e:
         r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)
     assert e.value.code == PT_EKERNEL
-    r2.enqueue(d_out.ptr, d_scene.ptr, n, basis)  # unchunked from here on
-    lab.check(lab.lib.pt_device_synchronize())
-    assert np.array_equal(_bits(d_out.download(np.float32, (h, w, 14))), _bits(ref))
     r2.destroy()
