@@ -316,7 +316,7 @@ def grid_header(spheres):
     f = u.view(np.float32)
     return {"valid": int(u[0]), "dims": (int(u[1]), int(u[2]), int(u[3])), "origin": (float(f[4]), float(f[5]), float(f[6])),
             "cell_size": float(f[7]), "slack": float(f[9]), "centre": (float(f[10]), float(f[11]), float(f[12])),
-            "far2": float(f[13]), "n_big": int(u[14]), "n_items": int(u[15])}
+            "far2": float(f[13]), "n_big": int(u[14]) & 0xFFFF, "n_entries": int(u[14]) >> 16, "n_items": int(u[15])}
 
 
 def upload_scene(spheres):

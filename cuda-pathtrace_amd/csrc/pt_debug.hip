@@ -153,7 +153,7 @@ extern "C" int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, u
   if (!d_spheres || !header_out || n_spheres < 1) return pt_fail(PT_EINVAL, "pt_debug_grid_header: bad arguments");
   uint32_t* d = nullptr;
   PT_HIPD(hipMalloc((void**)&d, pt_kernel_accel_bytes()));
-  hipError_t e = pt_launch_build_grid(d_spheres, n_spheres, d, nullptr, nullptr);
+  hipError_t e = pt_launch_build_grid(d_spheres, n_spheres, d, nullptr, true, nullptr);
   if (e == hipSuccess) e = hipMemcpy(header_out, d, 64, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   PT_HIPD(e);

@@ -64,52 +64,107 @@ struct GridHeader {  // 64 bytes, written by build_grid_kernel
   float ox, oy, oz, cs;
   float inv_cs, slack, cx, cy;
   float cz, far2;  // grid centre and (5E)^2: rays starting farther away are not admitted
-  uint32_t n_big, n_items;
+  uint32_t n_big, n_items;  // n_big: bits 0-15 = spheres outside the grid, bits 16-31 = entries of the pooled walk's table (cells + chained)
 };
 static_assert(sizeof(GridHeader) == 64, "GridHeader layout");
 
-// accel buffer: header | big[kGridMaxBig] u16 | cell_start[kGridMaxCells + 2] u16 | items[kGridMaxItems] u16
+// accel buffer: header | big[kGridMaxBig] u16 | cell_start[kGridMaxCells + 2] u16 | items[kGridMaxItems] u16 | cells[kGridMaxEntries] 2 x u32
+// `cells` (round 4, variant 13) is the cell table in the form the pooled walk reads with ONE ds_read_b64 per visit.  Entry c
+// (c < ncells) belongs to cell c; a cell with more than three registrations continues in chained entries behind the cells:
+//   word 0 = first sphere | next << 16 | k << 30     k = spheres in this entry (0..3), next = index of the entry the list
+//   word 1 = second sphere | third sphere << 16          continues in (0 = none; then k = 2: two spheres and the link)
+// 97 % of the cells of the 1000-sphere scene have at most three registrations and need nothing but their own entry.
+constexpr int kGridMaxEntries = 8191;  // 13 bits of `next`
 constexpr size_t kGridBigOff = sizeof(GridHeader);
 constexpr size_t kGridStartOff = kGridBigOff + kGridMaxBig * sizeof(uint16_t);
 constexpr size_t kGridItemsOff = kGridStartOff + (kGridMaxCells + 2) * sizeof(uint16_t);
-constexpr size_t kGridAccelBytes = kGridItemsOff + kGridMaxItems * sizeof(uint16_t);
+constexpr size_t kGridCellsOff = (kGridItemsOff + kGridMaxItems * sizeof(uint16_t) + 7) & ~(size_t)7;
+constexpr size_t kGridAccelBytes = kGridCellsOff + (size_t)(kGridMaxEntries + 1) * 2 * sizeof(uint32_t);
 
-// LDS image per workgroup: geometry of all n spheres, then the three tables (dword aligned)
-__host__ __device__ inline size_t grid_lds_bytes(int n) {
-  return (size_t)n * sizeof(float4) + (kGridAccelBytes - kGridBigOff);
+// How many table entries the pooled kernel's grid may have (cells + chained entries).  Variant 11's image has room for the maxima
+// of its own tables; variant 13's (8 bytes per entry, no registration list, plus 2.75 KB of test pool per wave) is sized so that
+// TWO 512-thread workgroups share a CU's 160 KB of LDS whatever the scene size (1000 spheres: 4 666 entries -- the build uses
+// 3 003 cells + about 100 chained; 2048 spheres: 2 570).
+constexpr int kPoolLdsTarget = 80 * 1024;  // per workgroup
+constexpr int kPoolRing = 512;             // ring entries per wave: a round adds at most 64 * 3 * PT_POOL_STEPS to fewer than 64 pending
+constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4;  // ring, best keys, runner-up estimates
+constexpr int kGridBigGeomBytes = kGridMaxBig * (int)sizeof(float4);
+__host__ __device__ inline int grid_max_entries(int n, bool pooled) {
+  if (!pooled) return kGridMaxEntries;  // (variant 11 does not stage the table)
+  const int fixed = kTablesF4 * (int)sizeof(float4) + (PT_GRID_BLOCK_THREADS / 64) * kPoolWaveBytes + kGridBigGeomBytes +
+                    kGridMaxBig * (int)sizeof(uint16_t) + 32;
+  int avail = kPoolLdsTarget - fixed - n * (int)sizeof(float4);
+  if (avail < 8192) avail = 8192;  // (never with n <= kGridMaxSpheres)
+  const int e = avail / 8;
+  return e > kGridMaxEntries ? kGridMaxEntries : e;
+}
+
+// LDS image per workgroup: geometry of all n spheres, the geometry of the spheres outside the grid once more (contiguous: no
+// index read on the way to it), then the tables (dword aligned)
+__host__ __device__ inline size_t grid_lds_bytes(int n, bool pooled) {
+  const size_t head = (size_t)n * sizeof(float4) + kGridBigGeomBytes + kGridMaxBig * sizeof(uint16_t);
+  if (pooled) return head + (size_t)grid_max_entries(n, true) * 8;
+  return head + (kGridCellsOff - kGridStartOff);
 }
 
 struct GridLds {
   bool valid;  // wave-uniform
   GridHeader h;
   const float4* geom;
+  const float4* bigg;  // geometry of the spheres outside the grid, in the order of `big`
   const uint16_t* big;
-  const uint16_t* cell_start;
+  const uint16_t* cell_start;  // variants 11, 12
   const uint16_t* items;
+  const uint2* cells;          // variant 13
 };
 
+template <bool POOLED>
 __device__ __forceinline__ GridLds stage_grid(const pt_sphere* __restrict__ spheres, int n, const uint32_t* __restrict__ accel,
                                               float4* lds) {
   GridLds g;
   g.h = *reinterpret_cast<const GridHeader*>(accel);
   g.valid = g.h.valid != 0u;
   g.geom = lds;
-  uint32_t* tab = reinterpret_cast<uint32_t*>(lds + n);
+  float4* bigg = lds + n;
+  g.bigg = bigg;
+  uint32_t* tab = reinterpret_cast<uint32_t*>(bigg + kGridMaxBig);
   g.big = reinterpret_cast<const uint16_t*>(tab);
-  g.cell_start = g.big + kGridMaxBig;
-  g.items = g.cell_start + (kGridMaxCells + 2);
+  const int ncells = (int)(g.h.nx * g.h.ny * g.h.nz);
+  uint32_t* after_big = tab + kGridMaxBig / 2;
+  if constexpr (POOLED) {
+    g.cells = reinterpret_cast<const uint2*>(after_big);  // (8-byte aligned: everything before it is a multiple of 16 bytes)
+    g.items = nullptr;  // not staged: the table's chained entries carry the long lists
+    g.cell_start = nullptr;
+  } else {
+    g.cell_start = reinterpret_cast<const uint16_t*>(after_big);
+    g.items = g.cell_start + (kGridMaxCells + 2);
+    g.cells = nullptr;
+  }
   if (!g.valid) return g;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const pt_sphere sp = spheres[i];
     lds[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
   }
+  const int n_big = (int)(g.h.n_big & 0xFFFFu);
+  for (int i = threadIdx.x; i < n_big; i += blockDim.x) {
+    const pt_sphere sp = spheres[reinterpret_cast<const uint16_t*>(accel + kGridBigOff / 4)[i]];
+    bigg[i] = make_float4(sp.pos[0], sp.pos[1], sp.pos[2], sp.radius * sp.radius);
+  }
   const uint32_t* src = accel + kGridBigOff / 4;
-  const int ncells = (int)(g.h.nx * g.h.ny * g.h.nz);
-  const int words_a = (kGridMaxBig + ncells + 2 + 1) / 2;  // big list + used part of cell_start
-  for (int i = threadIdx.x; i < words_a; i += blockDim.x) tab[i] = src[i];
-  const int item_w0 = (int)((kGridItemsOff - kGridBigOff) / 4);
-  const int words_i = ((int)g.h.n_items + 1) / 2;
-  for (int i = threadIdx.x; i < words_i; i += blockDim.x) tab[item_w0 + i] = src[item_w0 + i];
+  for (int i = threadIdx.x; i < kGridMaxBig / 2; i += blockDim.x) tab[i] = src[i];
+  if constexpr (POOLED) {
+    const int n_entries = (int)(g.h.n_big >> 16);
+    const uint32_t* src_cells = accel + kGridCellsOff / 4;
+    for (int i = threadIdx.x; i < 2 * n_entries; i += blockDim.x) after_big[i] = src_cells[i];
+  } else {
+    const int words_i = ((int)g.h.n_items + 1) / 2;
+    const uint32_t* src_items = accel + kGridItemsOff / 4;
+    const uint32_t* src_start = accel + kGridStartOff / 4;
+    const int words_s = (ncells + 2 + 1) / 2;
+    for (int i = threadIdx.x; i < words_s; i += blockDim.x) after_big[i] = src_start[i];
+    uint32_t* dst_items = after_big + (kGridMaxCells + 2) / 2;
+    for (int i = threadIdx.x; i < words_i; i += blockDim.x) dst_items[i] = src_items[i];
+  }
   __syncthreads();
   return g;
 }
@@ -121,17 +176,21 @@ __device__ __forceinline__ int f2ord(float f) {  // order-preserving float -> in
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : (int)(0x80000000u - (uint32_t)i)); }
 
+// entries chained behind a cell's own one in the pooled walk's table: a cell with count <= 3 needs none; otherwise every entry but
+// the last holds two spheres and the link, the last up to three
+__host__ __device__ inline uint32_t chained_entries(uint32_t count) { return count <= 3u ? 0u : (count - 2u) / 2u; }
+
 // eye_valid != 0: the camera position of the frame.  It only sizes the ADMISSION radius (header far2): every ray is checked
 // against far2 before it may use the grid, and the registration margins below are derived from that same radius, so a
 // wrong or missing hint costs time (more rays on the brute-force path, or fatter registrations), never correctness.
 __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_sphere* __restrict__ spheres, int n,
                                                                          uint32_t* __restrict__ accel, float eye_x, float eye_y,
-                                                                         float eye_z, int eye_valid) {
+                                                                         float eye_z, int eye_valid, int max_entries) {
   __shared__ uint32_t cnt[kGridMaxCells + 1];
   __shared__ uint32_t scan_tmp[kGridBuildThreads];
   __shared__ int bb[6];
   __shared__ float fsum;
-  __shared__ uint32_t n_small, n_big, total;
+  __shared__ uint32_t n_small, n_big, total, total_ext;
   __shared__ float s_cs;
   __shared__ uint32_t s_dims[3];
   __shared__ float enc[6];
@@ -147,6 +206,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     invalid();
     return;
   }
+  max_entries = max_entries < kGridMaxEntries ? max_entries : kGridMaxEntries;
   // reference radius: geometric mean (a handful of huge walls hardly move it)
   if (tid == 0) {
     fsum = 0.0f;
@@ -250,12 +310,12 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     const uint32_t nx = (uint32_t)fminf(ceilf(sx / cs), 512.0f), ny = (uint32_t)fminf(ceilf(sy / cs), 512.0f),
                    nz = (uint32_t)fminf(ceilf(sz / cs), 512.0f);
     const uint32_t ncells = (nx < 1 ? 1 : nx) * (ny < 1 ? 1 : ny) * (nz < 1 ? 1 : nz);
-    bool ok = ncells <= (uint32_t)kGridMaxCells;
+    bool ok = ncells <= (uint32_t)kGridMaxCells && ncells <= (uint32_t)max_entries;
     if (ok) {
       // count the registrations at this cell size
       __syncthreads();
       for (int c = tid; c <= kGridMaxCells; c += kGridBuildThreads) cnt[c] = 0u;
-      if (tid == 0) total = 0u;
+      if (tid == 0) total = 0u, total_ext = 0u;
       __syncthreads();
       const float inv = 1.0f / cs;
       uint32_t lt = 0;
@@ -281,6 +341,13 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
       atomicAdd(&total, lt);
       __syncthreads();
       ok = total <= (uint32_t)kGridMaxItems;
+      if (ok) {  // ... and the chained entries of the pooled walk's table (cells with more than three registrations)
+        uint32_t le = 0;
+        for (int c = tid; c < (int)ncells; c += kGridBuildThreads) le += chained_entries(cnt[c]);
+        atomicAdd(&total_ext, le);
+        __syncthreads();
+        ok = ncells + total_ext <= (uint32_t)max_entries;
+      }
       if (ok && tid == 0) {
         s_cs = cs;
         s_dims[0] = nx;
@@ -359,7 +426,52 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
           items[p] = (uint16_t)i;
         }
   }
+  __threadfence();
   __syncthreads();
+  // The cell table in the pooled walk's form (layout: head of this file).  Where a cell's chained entries start: exclusive scan
+  // of chained_entries(count) over the cells, with the scan code above (cnt[] is free again: the fill is over).
+  uint32_t n_ext = 0u;
+  {
+    constexpr int kPer = (kGridMaxCells + kGridBuildThreads - 1) / kGridBuildThreads;
+    uint32_t v[kPer], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int c = kPer * tid + j;
+      v[j] = c < (int)ncells ? chained_entries((uint32_t)cell_start[c + 1] - (uint32_t)cell_start[c]) : 0u;
+      sum += v[j];
+    }
+    __syncthreads();
+    scan_tmp[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kGridBuildThreads; off <<= 1) {
+      const uint32_t u = tid >= off ? scan_tmp[tid - off] : 0u;
+      __syncthreads();
+      scan_tmp[tid] += u;
+      __syncthreads();
+    }
+    uint32_t run = scan_tmp[tid] - sum;
+    n_ext = scan_tmp[kGridBuildThreads - 1];
+    uint32_t* cells = accel + kGridCellsOff / 4;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int c = kPer * tid + j;
+      if (c < (int)ncells) {
+        uint32_t p = cell_start[c], rem = (uint32_t)cell_start[c + 1] - p, idx = (uint32_t)c, next = ncells + run;
+        for (;;) {
+          const uint32_t k = rem <= 3u ? rem : 2u, link = rem <= 3u ? 0u : next;
+          const uint32_t i0 = k > 0u ? items[p] : 0u, i1 = k > 1u ? items[p + 1u] : 0u, i2 = k > 2u ? items[p + 2u] : 0u;
+          cells[2 * idx] = i0 | (link << 16) | (k << 30);
+          cells[2 * idx + 1] = i1 | (i2 << 16);
+          if (link == 0u) break;
+          idx = link;
+          next++;
+          p += 2u;
+          rem -= 2u;
+        }
+      }
+      run += v[j];
+    }
+  }
   if (tid == 0) {
     GridHeader h;
     h.valid = 1u;
@@ -376,7 +488,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     h.cy = ctr[1];
     h.cz = ctr[2];
     h.far2 = far * far;
-    h.n_big = n_big;
+    h.n_big = n_big | ((ncells + n_ext) << 16);
     h.n_items = total;
     *hdr = h;
   }
@@ -419,6 +531,8 @@ struct Near2 {
 // near2_exact() decides it with the reference's own expression.  (Until round 2 a doubt anywhere sent the lane to the
 // literal loop over ALL spheres of the scene: 5e-4 of the lanes per bounce at 1000 spheres -- one lane in 2.4 % of the
 // wave-bounces -- and with it a quarter of the frame time in the closed and 40 % in the open configuration.)
+// ONCE: the caller meets every sphere at most once (the list of spheres outside the grid): no leader check.
+template <bool ONCE = false>
 __device__ __forceinline__ bool near2_test(Near2& s, const float4 g, int i, F3 o, F3 d, float a4, float Tlim_hi) {
   const float INF = __builtin_inff();
   const F3 off = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
@@ -428,7 +542,7 @@ __device__ __forceinline__ bool near2_test(Near2& s, const float4 g, int i, F3 o
   const float a4c = a4 * c;
   const float dacc = fmaf(-a4, c, bb);
   // a sphere can sit in several cells: the current leader must not be entered again as its own runner-up
-  const bool cand = ((int)__float_as_uint(dacc) >= 0) & !((i == s.i1) & (s.T1 < INF));
+  const bool cand = ((int)__float_as_uint(dacc) >= 0) & (ONCE || !((i == s.i1) & (s.T1 < INF)));
   const float sq = __builtin_amdgcn_sqrtf(dacc);
   const float e = fmaf(b, b, -bb);
   const float num = a4c + e;
@@ -502,9 +616,11 @@ struct GridWalk {
   uint32_t n0, n1;                 // the list of the NEXT cell, fetched ahead of need (valid while have_next)
   bool have_next;
   bool walking;                    // the DDA can still move on: neither stopped nor out of the box
+  uint32_t e0, e1;                 // variant 13: the entry cell's table entry (layout: head of this file), count 0 if the ray misses the box
   __device__ __forceinline__ bool busy() const { return (k0 < k1) | have_next | walking; }
 };
 
+template <bool POOLED = false>
 __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a) {
   const float INF = __builtin_inff();
   const float two_a = 2.0f * a, a4 = 4.0f * a;
@@ -514,19 +630,19 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   w.s = Near2{INF, INF, 0};
   // spheres outside the grid (walls, very large or very small ones): every lane tests all of them
   {
-    const int nb = (int)G.h.n_big;  // wave-uniform
+    const int nb = (int)(G.h.n_big & 0xFFFFu);  // wave-uniform
     int k = 0;
     for (; k + 2 <= nb; k += 2) {  // in pairs: two independent dependency chains per trip
       const int i = (int)G.big[k], j = (int)G.big[k + 1];
-      const float4 gi = G.geom[i], gj = G.geom[j];
-      const bool di = near2_test(w.s, gi, i, o, d, a4, Tlim_hi);
-      const bool dj = near2_test(w.s, gj, j, o, d, a4, Tlim_hi);
+      const float4 gi = G.bigg[k], gj = G.bigg[k + 1];  // (their own contiguous copy: the geometry does not wait for the index)
+      const bool di = near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi);
+      const bool dj = near2_test<true>(w.s, gj, j, o, d, a4, Tlim_hi);
       if (__builtin_expect(di | dj, 0)) near2_resolve(w.s, (di ? 1u : 0u) | (dj ? 2u : 0u), gi, i, gj, j, gj, j, o, d, a, Tlim_hi);
     }
     if (k < nb) {
       const int i = (int)G.big[k];
-      const float4 gi = G.geom[i];
-      if (__builtin_expect(near2_test(w.s, gi, i, o, d, a4, Tlim_hi), 0)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);
+      const float4 gi = G.bigg[k];
+      if (__builtin_expect(near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi), 0)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);
     }
   }
   // clip against the grid box
@@ -579,13 +695,22 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   cidx = active ? cidx : 0;
   w.cidx = cidx;
   w.left = left;
-  w.k0 = G.cell_start[cidx], w.k1 = G.cell_start[cidx + 1];
-  if (!active) w.k1 = w.k0;
+  w.e0 = 0u, w.e1 = 0u;
+  w.k0 = 0u, w.k1 = 0u;
+  if constexpr (POOLED) {
+    const uint2 e = G.cells[cidx];
+    w.e0 = active ? e.x : 0u;
+    w.e1 = e.y;
+  } else {
+    w.k0 = G.cell_start[cidx], w.k1 = G.cell_start[cidx + 1];
+    if (!active) w.k1 = w.k0;
+  }
   w.n0 = 0, w.n1 = 0;
   w.have_next = false;
 #ifdef PT_TIMING_ONLY_NO_WALK   // never defined in a shipped build: what the kernel costs without the grid walk
   active = false;
   w.k1 = w.k0;
+  w.e0 = 0u;
 #endif
   w.walking = active;
   PT_STAT(0, 1);
@@ -773,45 +898,39 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 //    loser of each exchange goes to the runner-up slot with ds_min_u32.  Best and runner-up are the two smallest elements
 //    of the MULTISET of tested keys, so they do not depend on the order in which the wave happened to test them; equal keys
 //    are the same sphere met in two cells and are entered once (what near2_test's leader check does);
-//  * the owner reads its best estimate back (one ds_read) when it evaluates the stop rule of its next step.  That value
-//    may be stale by the entries still in the ring: the rule then fires later, never earlier -- more cells, more tests, the
-//    same superset argument as the look-ahead step of variant 11 (exactness appendix A.6 (iii-b)).
-//  * WALKS can move too (PT_POOL_SPLITS > 0: lab library only, see there why).  The step loop runs as long as the wave's longest walk (26 rounds for a mean of 7 steps): once at most
-//    PT_POOL_SPLIT_BELOW lanes are still walking, every lane with nothing left to do takes over the FAR HALF of the remaining
-//    parameter range of a walking lane -- it fetches that lane's home ray with ds_bpermute, enters the grid at the midpoint
-//    (minus the slack) with the entry-cell code of grid_begin, and from then on pushes entries tagged with the ray's HOME
-//    lane and stops by the home lane's best estimate, which all walkers of a ray share through the slot.  The donor walks on
-//    to the midpoint (plus the slack).  The cells visited are a superset of the single walker's (the ranges overlap by twice
-//    the slack; each walker stops only by the shared rule or at its range's end), so the tested spheres are too.
+//  * the owner reads its best estimate back after a drain, for the stop rule of its next steps.  That value may be stale by
+//    the entries still in the ring: the rule then fires later, never earlier -- more cells, more tests, the same superset
+//    argument as the look-ahead step of variant 11 (exactness appendix A.6 (iii-b)).
+// Round 4.  Counters (profiles/r04): the walk is ISSUE-bound, not latency-bound -- 71 vector instructions per round and cell
+// (24.6 rounds per wave-walk with 16.5 of 64 lanes stepping), most of them at the half rate (compares, selects), against 48 per
+// drain of 60 tests.  So the rounds were rebuilt for instruction count:
+//  * a cell's table entry carries its registrations inline (head of this file): one ds_read_b64 per visit instead of two index
+//    reads and up to three list reads with their address arithmetic, and the push takes its ring values from registers;
+//  * cells with more than three registrations (3 %) continue in chained entries: a lane that holds a link reads that entry
+//    instead of taking a DDA step -- no list ranges, no second code path;
+//  * a lane advances PT_POOL_STEPS = 2 cells per round: both steps are pure arithmetic on the DDA state, both entries are
+//    requested together and one wait, one loop trip and one round of bookkeeping serve them.  The stop rule of the second step
+//    sees the best estimate the first saw: at worst one cell more than strictly needed -- more tests, same result (A.6 (iii-b));
+//  * ring positions come from three compares and six chained v_mbcnt, the three stores of a push are unconditional (a lane that
+//    has fewer than three spheres writes garbage into slots that a later store of the same push overwrites: stores go out in
+//    descending slot order, and a slot's rightful owner always holds a lower slot number than the garbage that hits it);
+//  * after a drain the ring's remainder (less than a pass) moves to the ring's start, so positions need no wrap-around;
+//  * the best estimate is read back only after a drain (nothing else can change it).
+// (The walk-range hand-over of round 3's lab build -- idle lanes taking the far half of a busy lane's walk -- is gone: a
+// measured negative result)
 // Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
 // expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
 // (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
-constexpr int kPoolRing = 256;  // ring entries per wave: a round adds at most 64 * kPoolPush to fewer than 64 pending
-#ifndef PT_POOL_PUSH
-#define PT_POOL_PUSH 3
+#ifndef PT_POOL_STEPS
+#define PT_POOL_STEPS 2
 #endif
-constexpr int kPoolPush = PT_POOL_PUSH;
-static_assert(64 * kPoolPush + 63 < kPoolRing + 1, "pool ring too small");
-constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4 + 64 * 4;  // ring, best keys, runner-up estimates, donor list
-#ifndef PT_POOL_SPLITS
-// at most this many hand-overs of walk ranges per walk (0: never).  A measured negative result, compiled into the lab
-// library only (csrc/Makefile): at 1000 spheres + walls it takes the step rounds of a walk from 25.7 to 16.0 (16.7 lanes are
-// handed a range per walk) and the frame from 12.48 to 12.61 ms at 32 spp (open: 5.01 -> 5.44) -- the entry-cell code the
-// takers run and the cells both halves visit cost what the shorter loop saves (profiles/r03/README.md)
-#define PT_POOL_SPLITS 0
-#endif
-#ifndef PT_POOL_SPLIT_BELOW
-#define PT_POOL_SPLIT_BELOW 36 // ... considered when at most this many lanes of the wave are still walking
-#endif
-#ifndef PT_POOL_SPLIT_CELLS
-#define PT_POOL_SPLIT_CELLS 4.0f  // ... for walks with more than about this many cells left
-#endif
+static_assert(63 + 64 * 3 * PT_POOL_STEPS + 2 <= kPoolRing, "pool ring too small");
+static_assert(PT_POOL_STEPS == 1 || PT_POOL_STEPS == 2, "the link queue has two slots");
 
 struct PoolLds {
   uint32_t* ring;            // [kPoolRing] (owner lane << 16) | sphere index
   unsigned long long* key1;  // [64] per owner lane: (bits of the smallest estimate << 32) | its sphere
   uint32_t* t2;              // [64] per owner lane: bits of the second smallest estimate
-  uint32_t* donors;          // [64] lanes that hand the far half of their walk to an idle lane, by rank
 };
 constexpr unsigned long long kPoolEmpty = 0x7F800000FFFFFFFFull;  // +inf, no sphere
 
@@ -821,40 +940,48 @@ __device__ __forceinline__ PoolLds pool_of_wave(void* workgroup_base) {
   p.key1 = reinterpret_cast<unsigned long long*>(b);
   p.ring = reinterpret_cast<uint32_t*>(b + 64 * 8);
   p.t2 = reinterpret_cast<uint32_t*>(b + 64 * 8 + kPoolRing * 4);
-  p.donors = reinterpret_cast<uint32_t*>(b + 64 * 8 + kPoolRing * 4 + 64 * 4);
   return p;
 }
-
-#ifdef PT_GRID_STATS
-#define PT_POOL_STAT(i, v) PT_STAT(i, v)
-#else
-#define PT_POOL_STAT(i, v) do { } while (0)
-#endif
 
 __device__ __forceinline__ float bperm_f(int byte_addr, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
-// The walk of variant 13 (between grid_begin and grid_end).  Every lane that is in the function helps testing; `walk`
-// belongs to the lane's own ray (walk.walking false and an empty list: a ray that misses the grid box).
+// One DDA step (grid_trips: same rule, same arithmetic); returns whether the lane still walks, i.e. stands in a new cell.
+// (A free function with the strides BY VALUE: inside a lambda that captures them by reference the select between them becomes a
+// select of addresses and a load from scratch memory, see grid_trips.)
+__device__ __forceinline__ bool dda_step(float& tmax0, float& tmax1, float& tmax2, float tdel0, float tdel1, float tdel2, int& cidx,
+                                         int cs0, int cs1, int cs2, uint32_t& left, float T1, float slack_t, float two_a, float Tcap) {
+  const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
+  const float reach = (t_exit - slack_t) * two_a;
+  // nothing that could still matter lies beyond the cell being left: stop
+  const bool stop = (T1 * 1.0000077f < reach) | (reach > Tcap);
+  const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
+  const bool a1 = !a0 & (tmax1 <= tmax2);
+  tmax0 = a0 ? tmax0 + tdel0 : tmax0;
+  tmax1 = a1 ? tmax1 + tdel1 : tmax1;
+  tmax2 = (a0 | a1) ? tmax2 : tmax2 + tdel2;
+  cidx += a0 ? cs0 : (a1 ? cs1 : cs2);
+  left -= a0 ? 1u : (a1 ? (1u << 10) : (1u << 20));
+  return !stop & ((left & 0x20080200u) == 0x20080200u);
+}
+
+// The walk of variant 13 (between grid_begin<true> and grid_end).  Every lane that is in the function helps testing; `walk`
+// belongs to the lane's own ray (walk.walking false and an empty entry: a ray that misses the grid box).
 __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds& G, const PoolLds& P, F3 o, F3 d) {
+  constexpr int K = PT_POOL_STEPS;
   const float INF = __builtin_inff();
   const int lane = threadIdx.x & 63;
-  const float a4 = 4.0f * walk.a;  // of the lane's OWN ray: what the testers fetch
-  // the walk this lane is advancing: its own ray's at first, later possibly the far part of another lane's (see above)
-  float two_a = 2.0f * walk.a;
-  float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
-  float Tcap = 1000000.0f * two_a * 1.0000153f;  // the walk ends where 2a t passes this: the 1e6 limit, or the range handed to another lane
-  int home = lane;                                // the lane whose ray this is: tags the ring entries, owns the result slots
+  const float a4 = 4.0f * walk.a;  // what the testers fetch
+  const float two_a = 2.0f * walk.a;
+  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
+  const float Tcap = 1000000.0f * two_a * 1.0000153f;  // the walk ends where 2a t passes the 1e6 limit
   float tmax0 = walk.tmax0, tmax1 = walk.tmax1, tmax2 = walk.tmax2;
-  float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
+  const float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
   int cidx = walk.cidx;
-  int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
-  uint32_t left = walk.left, k0 = walk.k0, k1 = walk.k1;
+  const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
+  uint32_t left = walk.left;
   bool walking = walk.walking;
-#if PT_POOL_SPLITS > 0
-  int splits = 0;  // wave-uniform
-#endif
   // lanes of this wave that are here (the others are on the brute-force path, or their pixel is finished): ranks, not lane
   // numbers, index the ring
   const uint64_t here = __builtin_amdgcn_ballot_w64(true);
@@ -865,210 +992,159 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   __hip_atomic_store(P.key1 + lane, walk.s.T1 < INF ? (((unsigned long long)__float_as_uint(walk.s.T1) << 32) | (uint32_t)walk.s.i1) : kPoolEmpty,
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_store(P.t2 + lane, __float_as_uint(walk.s.T2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  uint32_t head = 0u, tail = 0u;  // wave-uniform ring positions (slot = position mod kPoolRing)
-  float T1 = walk.s.T1;           // the owner's best estimate as of the last drain (read back at the end of every round)
+  uint32_t links = 0u;   // chained table entries this lane still has to follow: a queue of two 16-bit slots (see (3))
+  uint32_t tail = 0u;    // wave-uniform: entries in the ring, which always starts at slot 0 when a push begins
+  float T1 = walk.s.T1;  // the owner's best estimate as of the last drain
+  const uint32_t tag = (uint32_t)lane << 16;
   PT_HIST_DECL;
+
+  // entries in hand: the cell(s) the lane has just stepped into, or the chained entries it has followed
+  uint32_t e0[K], e1[K];
+  e0[0] = walk.e0, e1[0] = walk.e1;
+#pragma unroll
+  for (int k = 1; k < K; k++) e0[k] = 0u, e1[k] = 0u;
   for (;;) {
-    // (1) one step for every lane whose list is used up
-    // (Measured and dropped: requesting the next cell's list a round ahead, as variant 11 does, so that the two LDS round
-    // trips of a round overlap -- the extra cell every lane then runs ahead costs more tests than the overlap saves:
-    // 12.5 -> 13.3 ms at 32 spp, open 4.9 -> 5.2.)
-    const bool need = walking & (k0 >= k1);
-    if (__builtin_amdgcn_ballot_w64(need) != 0) {
-      PT_STATW(3, 1);
-      PT_STATW(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(need)));
-      PT_HIST_LANE(hist_rounds, 1);
-      if (need) {
-        PT_HIST_LANE(hist_steps, 1);
-        const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
-        const float reach = (t_exit - slack_t) * two_a;
-        const bool stop = (T1 * 1.0000077f < reach) | (reach > Tcap);
-        const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
-        const bool a1 = !a0 & (tmax1 <= tmax2);
-        tmax0 = a0 ? tmax0 + tdel0 : tmax0;
-        tmax1 = a1 ? tmax1 + tdel1 : tmax1;
-        tmax2 = (a0 | a1) ? tmax2 : tmax2 + tdel2;
-        cidx += a0 ? cs0 : (a1 ? cs1 : cs2);
-        left -= a0 ? 1u : (a1 ? (1u << 10) : (1u << 20));
-        walking = !stop & ((left & 0x20080200u) == 0x20080200u);
-        if (walking) {
-          k0 = G.cell_start[cidx];
-          k1 = G.cell_start[cidx + 1];
+    // (1) append the entries' spheres to the ring.  Slots: a lane's are consecutive and start at the exclusive prefix sum of the
+    // counts, which three compares and six chained v_mbcnt give (count >= 1, >= 2, >= 3: the count sits in the top two bits).
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint64_t m1 = __builtin_amdgcn_ballot_w64(e0[k] >= 0x40000000u);
+      if (m1 != 0) {
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(e0[k] >= 0x80000000u), m3 = __builtin_amdgcn_ballot_w64(e0[k] >= 0xC0000000u);
+        uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, tail));
+        pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, pos));
+        pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, pos));
+        PT_HIST_LANE(hist_tests, (int)(e0[k] >> 30));
+        if (e0[k] >= 0x40000000u) {
+          // (descending, and THREE instructions: see the head of this section.  The barriers keep the compiler from fusing two of
+          // the stores into one ds_write2_b32, inside which a lane's garbage and its neighbour's rightful value would race.)
+          uint32_t* slot = P.ring + pos;
+          slot[2] = tag | (e1[k] >> 16);
+          asm volatile("" ::: "memory");
+          slot[1] = tag | (e1[k] & 0xFFFFu);
+          asm volatile("" ::: "memory");
+          slot[0] = tag | (e0[k] & 0xFFFFu);
         }
+        tail += (uint32_t)(__builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+        // a link goes to the queue slot of its entry: entry 0's to the high half (where the entry word already has it), entry 1's
+        // to the low half.  (Only an entry with spheres has a link; the slot is free: see (3).)
+        if (k == 0) links |= e0[k] & 0x1FFF0000u; else links |= (e0[k] >> 16) & 0x1FFFu;
       }
     }
-    // (2) append up to kPoolPush spheres of every lane's list to the ring
-    const uint32_t c = k0 < k1 ? ((k1 - k0) < (uint32_t)kPoolPush ? (k1 - k0) : (uint32_t)kPoolPush) : 0u;
-    const bool any_list = __builtin_amdgcn_ballot_w64(c != 0u) != 0;
-    const bool any_walking = __builtin_amdgcn_ballot_w64(walking) != 0;
-    if (any_list) {
-      PT_HIST_LANE(hist_tests, (int)c);
-      uint32_t it[kPoolPush];
-#pragma unroll
-      for (int j = 0; j < kPoolPush; j++) it[j] = G.items[(uint32_t)j < c ? k0 + (uint32_t)j : 0u];  // all reads first
-      // ring positions: a lane's entries are consecutive, starting at the exclusive prefix sum of c over the lanes, which two
-      // ballots give (c = c0 + 2 c1 <= 3): prefix = mbcnt(ballot(c0)) + 2 mbcnt(ballot(c1))
-      static_assert(kPoolPush <= 3, "the prefix below sums two count bits");
-      const uint64_t m0 = __builtin_amdgcn_ballot_w64((c & 1u) != 0u), m1 = __builtin_amdgcn_ballot_w64((c & 2u) != 0u);
-      const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-      const uint32_t p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-      const uint32_t pos = tail + p0 + 2u * p1;
-      const uint32_t tag = (uint32_t)home << 16;
-#pragma unroll
-      for (int j = 0; j < kPoolPush; j++)
-        if (c > (uint32_t)j) P.ring[(pos + (uint32_t)j) & (uint32_t)(kPoolRing - 1)] = tag | it[j];
-      tail += (uint32_t)__builtin_popcountll(m0) + 2u * (uint32_t)__builtin_popcountll(m1);
-      k0 += c;
-    }
-    // (3) drain: whole passes while the ring holds one; everything once nobody can add to it any more
-    const bool last = !any_list & !any_walking;
-    while ((tail - head) >= (last ? 1u : n_here)) {
-      const uint32_t n = (tail - head) < n_here ? (tail - head) : n_here;
-      const bool valid = rank < n;
-      PT_STATW(1, 1);
-      PT_STATW(2, n);
-      PT_HIST_LANE(hist_trips, 1);
-      const uint32_t e = P.ring[(head + rank) & (uint32_t)(kPoolRing - 1)];
-      head += n;
-      const int owner = valid ? (int)(e >> 16) : lane;
-      const int i = valid ? (int)(e & 0xFFFFu) : 0;
-      const float4 g = G.geom[i];
-      const int oa = owner << 2;
-      const F3 ro = mk3(bperm_f(oa, o.x), bperm_f(oa, o.y), bperm_f(oa, o.z));
-      const F3 rd = mk3(bperm_f(oa, d.x), bperm_f(oa, d.y), bperm_f(oa, d.z));
-      const float ra4 = bperm_f(oa, a4);
-      const float rTlim_hi = 1000000.0f * (0.5f * ra4) * 1.0000153f;  // the owner's own Tlim_hi: same operands, same operations
-      // the float screen of near2_test
-      const F3 off = mk3(ro.x - g.x, ro.y - g.y, ro.z - g.z);
-      const float b = 2.0f * dot(rd, off);
-      const float cc = dot(off, off) - g.w;
-      const float bb = b * b;
-      const float a4c = ra4 * cc;
-      const float dacc = fmaf(-ra4, cc, bb);
-      const bool cand = valid & ((int)__float_as_uint(dacc) >= 0);
-      const float sq = __builtin_amdgcn_sqrtf(dacc);
-      const float ee = fmaf(b, b, -bb);
-      const float num = a4c + ee;
-      const float TA = copysign_neg_b3(sq, b) - b;  // -q (near2_test)
-      const float TB = num * __builtin_amdgcn_rcpf(TA);
-      const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
-      const uint32_t tbits = ta < tb ? ta : tb;  // the smaller positive root's bits, sign bit set or NaN bits if none (near2_test)
-      float T = __uint_as_float(tbits);
-      const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);
-      bool ok = cand & sure & (tbits < __float_as_uint(rTlim_hi));
-      if (__builtin_expect(cand & !sure, 0)) {  // near2_exact: the reference's own test, 2a*t in place of the estimate
-        float t = 0.0f;
-        const float ra = 0.25f * ra4;
-        const bool h = intersect_sphere(ro, rd, ra, g, t);
-        T = (2.0f * ra) * t;
-        ok = h & (t > 0.0f) & (T < rTlim_hi);
-      }
-      if (ok) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)i;
-        const unsigned long long old = __hip_atomic_fetch_min(P.key1 + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (old != key) {  // (an equal key is the same sphere met in another cell: entered once)
-          const unsigned long long loser = old > key ? old : key;
-          __hip_atomic_fetch_min(P.t2 + owner, (uint32_t)(loser >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (2) drain: whole passes while the ring holds one; everything once nobody can add to it any more
+    const bool fin = __builtin_amdgcn_ballot_w64(walking | (links != 0u)) == 0;
+    if (tail >= (fin ? 1u : n_here)) {
+      uint32_t head = 0u;
+      do {
+        const uint32_t n = (tail - head) < n_here ? (tail - head) : n_here;
+        const bool valid = rank < n;
+        PT_STATW(1, 1);
+        PT_STATW(2, n);
+        PT_HIST_LANE(hist_trips, 1);
+        const uint32_t e = P.ring[head + rank];
+        head += n;
+        const int owner = valid ? (int)(e >> 16) : lane;
+        const int i = valid ? (int)(e & 0xFFFFu) : 0;
+        const float4 g = G.geom[i];
+        const int oa = owner << 2;
+        const F3 ro = mk3(bperm_f(oa, o.x), bperm_f(oa, o.y), bperm_f(oa, o.z));
+        const F3 rd = mk3(bperm_f(oa, d.x), bperm_f(oa, d.y), bperm_f(oa, d.z));
+        const float ra4 = bperm_f(oa, a4);
+        const float rTlim_hi = 1000000.0f * (0.5f * ra4) * 1.0000153f;  // the owner's own Tlim_hi: same operands, same operations
+        // the float screen of near2_test
+        const F3 off = mk3(ro.x - g.x, ro.y - g.y, ro.z - g.z);
+        const float b = 2.0f * dot(rd, off);
+        const float cc = dot(off, off) - g.w;
+        const float bb = b * b;
+        const float a4c = ra4 * cc;
+        const float dacc = fmaf(-ra4, cc, bb);
+        const bool cand = valid & ((int)__float_as_uint(dacc) >= 0);
+        const float sq = __builtin_amdgcn_sqrtf(dacc);
+        const float ee = fmaf(b, b, -bb);
+        const float num = a4c + ee;
+        const float TA = copysign_neg_b3(sq, b) - b;  // -q (near2_test)
+        const float TB = num * __builtin_amdgcn_rcpf(TA);
+        const uint32_t ta = __float_as_uint(TA), tb = __float_as_uint(TB);
+        const uint32_t tbits = ta < tb ? ta : tb;  // the smaller positive root's bits, sign bit set or NaN bits if none (near2_test)
+        float T = __uint_as_float(tbits);
+        const bool sure = fabsf(a4c) > fmaf(bb, 1.1920929e-07f, 1e-30f);
+        bool ok = cand & sure & (tbits < __float_as_uint(rTlim_hi));
+        if (__builtin_expect(cand & !sure, 0)) {  // near2_exact: the reference's own test, 2a*t in place of the estimate
+          float t = 0.0f;
+          const float ra = 0.25f * ra4;
+          const bool h = intersect_sphere(ro, rd, ra, g, t);
+          T = (2.0f * ra) * t;
+          ok = h & (t > 0.0f) & (T < rTlim_hi);
         }
-      }
-    }
-    if (last) break;
-#if PT_POOL_SPLITS > 0
-    // (4) hand walk ranges to idle lanes (see the head of this section)
-    if (splits < PT_POOL_SPLITS) {
-      const uint64_t wm = __builtin_amdgcn_ballot_w64(walking);
-      const int nw = __builtin_popcountll(wm);
-      if (nw != 0 && nw <= PT_POOL_SPLIT_BELOW && nw < (int)n_here) {
-        // what a walking lane has left: from the exit of the cell it stands in to where the shared stop rule, its range's end or
-        // the box would end it.  Only the BALANCE of the hand-over depends on these numbers, never the coverage: the taker walks
-        // from the midpoint until the stop rule, its inherited cap or the box ends it, the donor until the midpoint.
-        const float t_cur = fminf(fminf(tmax0, tmax1), tmax2);
-        const float l0 = (float)(left & 0x1FFu), l1 = (float)((left >> 10) & 0x1FFu), l2 = (float)((left >> 20) & 0x1FFu);
-        const float t_box = fminf(fminf(tdel0 < INF ? tmax0 + l0 * tdel0 : INF, tdel1 < INF ? tmax1 + l1 * tdel1 : INF),
-                                  tdel2 < INF ? tmax2 + l2 * tdel2 : INF);
-        const float inv_2a = __builtin_amdgcn_rcpf(two_a);
-        const float t_end = fminf(fminf(t_box, Tcap * inv_2a), T1 * inv_2a + slack_t);
-        const float tdel_min = fminf(fminf(tdel0, tdel1), tdel2);
-        const bool donor = walking & (t_end - t_cur > PT_POOL_SPLIT_CELLS * tdel_min) & (t_end < INF);
-        const bool idle = !walking & (k0 >= k1);
-        const uint64_t dm = __builtin_amdgcn_ballot_w64(donor), im = __builtin_amdgcn_ballot_w64(idle);
-        const int nd = __builtin_popcountll(dm), ni = __builtin_popcountll(im);
-        const int np = nd < ni ? nd : ni;
-        if (np > 0) {
-          splits++;
-          PT_POOL_STAT(7, np);  // (stats build: slot 7 then counts lanes handed a range, not brute-force waves)
-          const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-          const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-          const bool gives = donor & (rd < (uint32_t)np), takes = idle & (ri < (uint32_t)np);
-          const float t_mid = 0.5f * (t_cur + t_end);
-          if (gives) P.donors[rd] = (uint32_t)lane;
-          const int from = takes ? (int)P.donors[ri] : lane;  // (DS operations of one wave execute in order)
-          // the donor's walk parameters, then the ray of the donor's HOME lane (whose o, d registers are its own ray's, always)
-          const int fa = from << 2;
-          const int n_home = __builtin_amdgcn_ds_bpermute(fa, home);
-          const float n_mid = bperm_f(fa, t_mid), n_cap = bperm_f(fa, Tcap);
-          const int ha = n_home << 2;
-          const F3 ho = mk3(bperm_f(ha, o.x), bperm_f(ha, o.y), bperm_f(ha, o.z));
-          const F3 hd = mk3(bperm_f(ha, d.x), bperm_f(ha, d.y), bperm_f(ha, d.z));
-          if (gives) Tcap = fminf(Tcap, (t_mid + 2.0f * slack_t) * two_a);  // (after the taker has read the old cap)
-          if (takes) {
-            home = n_home;
-            const float ha_ = dot(hd, hd);
-            two_a = 2.0f * ha_;
-            slack_t = G.h.slack * __builtin_amdgcn_rsqf(ha_);
-            Tcap = n_cap;
-            const float t_start = fmaxf(n_mid - 2.0f * slack_t, 0.0f);
-            // the entry cell and the DDA state of grid_begin, at t_start
-            const float gmin[3] = {G.h.ox, G.h.oy, G.h.oz};
-            const int dims[3] = {(int)G.h.nx, (int)G.h.ny, (int)G.h.nz};
-            const float oo[3] = {ho.x, ho.y, ho.z}, dd[3] = {hd.x, hd.y, hd.z};
-            const float tiny = __builtin_amdgcn_sqrtf(ha_) * 9.094947e-13f;
-            const int stride[3] = {1, dims[0], dims[0] * dims[1]};
-            int ncidx = 0;
-            uint32_t nleft = 0x20080200u;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const bool par = !(fabsf(dd[k]) > tiny);
-              const float inv = par ? 0.0f : __builtin_amdgcn_rcpf(dd[k]);
-              const float p = oo[k] + dd[k] * t_start;
-              int ci = (int)floorf((p - gmin[k]) * G.h.inv_cs);
-              ci = ci < 0 ? 0 : (ci >= dims[k] ? dims[k] - 1 : ci);
-              const bool fwd = dd[k] > 0.0f;
-              const float bnd = gmin[k] + (float)(ci + (fwd ? 1 : 0)) * G.h.cs;
-              const float tm = par ? INF : (bnd - oo[k]) * inv;
-              const float td = par ? INF : G.h.cs * fabsf(inv);
-              const int sk = fwd ? stride[k] : -stride[k];
-              if (k == 0) { tmax0 = tm; tdel0 = td; cs0 = sk; }
-              if (k == 1) { tmax1 = tm; tdel1 = td; cs1 = sk; }
-              if (k == 2) { tmax2 = tm; tdel2 = td; cs2 = sk; }
-              ncidx += ci * stride[k];
-              nleft |= (uint32_t)(fwd ? dims[k] - 1 - ci : ci) << (10 * k);
-            }
-            cidx = ncidx;
-            left = nleft;
-            k0 = G.cell_start[cidx];
-            k1 = G.cell_start[cidx + 1];
-            walking = true;
+        if (ok) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)i;
+          const unsigned long long old = __hip_atomic_fetch_min(P.key1 + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old != key) {  // (an equal key is the same sphere met in another cell: entered once)
+            const unsigned long long loser = old > key ? old : key;
+            __hip_atomic_fetch_min(P.t2 + owner, (uint32_t)(loser >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
+      } while ((tail - head) >= (fin ? 1u : n_here));
+      // what is left (less than a pass) moves to the ring's start (DS operations of one wave execute in order)
+      const uint32_t rest = tail - head;
+      if (rest != 0u) {
+        const uint32_t v = P.ring[head + (rank < rest ? rank : 0u)];
+        if (rank < rest) P.ring[rank] = v;
+      }
+      tail = rest;
+      // (nothing but a drain changes a best estimate)
+      T1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(P.key1 + lane) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    if (fin) break;
+    // (3) the next entries.  A lane that holds links follows ONE of them (the entry it reads may add another: its round ends
+    // there) -- the high slot's if there is one, so that the slot its new entry 0 may write a link to is free; a lane without
+    // links takes K DDA steps.  At most two links are ever pending: two from the K cells of a stepping round, or the one left
+    // over plus the one the followed entry brought.
+    PT_STATW(3, 1);
+    PT_STATW(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(walking | (links != 0u))));
+    PT_HIST_LANE(hist_rounds, 1);
+    uint32_t cur = 0u;
+    if (__builtin_amdgcn_ballot_w64(links != 0u) != 0) {
+      const uint32_t hi = links >> 16;
+      cur = hi != 0u ? hi : links;
+      links = hi != 0u ? (links & 0xFFFFu) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) e0[k] = 0u, e1[k] = 0u;
+    const bool chain = cur != 0u;
+    bool go = chain;
+    if (!chain & walking) {
+      PT_HIST_LANE(hist_steps, 1);
+      walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, left, T1, slack_t, two_a, Tcap);
+      go = walking;
+    }
+    if (go) {
+      const uint2 e = G.cells[chain ? (int)cur : cidx];
+      e0[0] = e.x, e1[0] = e.y;
+    }
+#pragma unroll
+    for (int k = 1; k < K; k++) {
+      if (!chain & walking) {
+        PT_HIST_LANE(hist_steps, 1);
+        walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, left, T1, slack_t, two_a, Tcap);
+        if (walking) {
+          const uint2 e = G.cells[cidx];
+          e0[k] = e.x, e1[k] = e.y;
+        }
       }
     }
-#endif
-    // requested here, used by the next round's stop rule: the LDS latency hides behind the loop's own bookkeeping
-    T1 = __uint_as_float((uint32_t)(__hip_atomic_load(P.key1 + home, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
   }
   PT_HIST_END(true);
   const unsigned long long k = __hip_atomic_load(P.key1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   walk.s.T1 = __uint_as_float((uint32_t)(k >> 32));
   walk.s.i1 = walk.s.T1 < INF ? (int)(uint32_t)k : 0;
   walk.s.T2 = __uint_as_float(__hip_atomic_load(P.t2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-  (void)cidx;  // (the walk state is not handed back: it may be another ray's by now, and grid_end needs only the result)
 }
 
 __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
                                                             float& t_hit, int& idx) {
   GridWalk w;
-  grid_begin(w, G, o, d, a);
+  grid_begin<true>(w, G, o, d, a);
   grid_trips_pooled(w, G, pool_of_wave(sc.pool), o, d);
   return grid_end(w, sc, G, n, o, d, t_hit, idx);
 }

@@ -157,7 +157,8 @@ const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_b
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);
-hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */, hipStream_t stream);
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */,
+                                bool pooled /* for variant 13's LDS image (fewer cells at large n) */, hipStream_t stream);
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);

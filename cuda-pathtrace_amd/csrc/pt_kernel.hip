@@ -104,10 +104,10 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   constexpr bool kRegen = (VAR == 10 || VAR == 11 || VAR == 13);
   GridLds grid;
   if constexpr (VAR == 11 || VAR == 12 || VAR == 13) {  // the frame's grid, built by build_grid_kernel just before this launch
-    grid = stage_grid(a.spheres, a.n_spheres, a.accel, lds_scene + a.scene_lds_f4);  // after the two small tables
+    grid = stage_grid<VAR == 13>(a.spheres, a.n_spheres, a.accel, lds_scene + a.scene_lds_f4);  // after the two small tables
     sc.grid = &grid;
     if constexpr (VAR == 13)  // the test pool of each wave follows the grid image (16-byte aligned)
-      sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres) + 15) & ~(size_t)15);
+      sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres, true) + 15) & ~(size_t)15);
   }
 
   // Sample chunking (REF builds of variant 6, variant 13): workgroup blockIdx.x = chunk * n_blocks + block renders samples
@@ -846,9 +846,9 @@ static inline size_t scene_lds_f4(int n, int variant) {
 // what follows the scene image: one 64 x 14 float transpose slice per wave for the epilogue, or the
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
-  if (variant == 11 || variant == 12) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n) : 64;  // geometry + grid tables instead of the epilogue slice
+  if (variant == 11 || variant == 12) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n, false) : 64;  // geometry + grid tables instead of the epilogue slice
   if (variant == 13)  // + per wave the test ring and the owners' result slots
-    return (n <= pt::kGridMaxSpheres ? ((pt::grid_lds_bytes(n) + 15) & ~(size_t)15) : 64) + (PT_GRID_BLOCK_THREADS / 64) * pt::kPoolWaveBytes;
+    return (n <= pt::kGridMaxSpheres ? ((pt::grid_lds_bytes(n, true) + 15) & ~(size_t)15) : 64) + (PT_GRID_BLOCK_THREADS / 64) * pt::kPoolWaveBytes;
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
   return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
@@ -965,9 +965,10 @@ int pt_kernel_max_spheres(int variant) {
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
 }
 
-hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, hipStream_t stream) {
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, bool pooled, hipStream_t stream) {
+  // (table entries the LDS image of the kernel that will walk this grid has room for)
   hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel, eye ? eye[0] : 0.0f,
-                     eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0);
+                     eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0, pt::grid_max_entries(n, pooled));
   return hipGetLastError();
 }
 
@@ -993,7 +994,7 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   }
   if (variant == 11 || variant == 12 || variant == 13) {  // this frame's grid (the scene may have changed since the last one)
     if (!a.accel) return hipErrorInvalidValue;
-    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, stream);
+    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, variant == 13, stream);
     if (e != hipSuccess) return e;
   }
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);
