@@ -316,6 +316,9 @@ def main():
 
         m, elapsed, kernel_s = measure(rng_mode)
         exchange = m.backend()
+        fs = m.frame_stats()  # pt_mgpu_render is synchronous: every frame is one unpipelined frame
+        latency = {"frame_latency_ms": round(elapsed / args.steps * 1e3, 3), "exchange_exposed_ms": round(fs["exposed_ms"], 3),
+                   "bands_per_tile": fs["bands"]} if n_gpus > 1 else None
         rb, re_ = m.tile(0)["rows"]
         # a single-device renderer of rank 0's tile only to report which kernel that tile runs
         probe = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=rng_mode, row_begin=rb, row_end=re_, variant=args.variant, persist_rng=False, max_bounces=MAXB)
@@ -337,7 +340,7 @@ def main():
         rb, re_ = fgs[0].rows
         step_no = [0]
 
-        def measure(mode, fast_math=False):
+        def measure(mode, fast_math=False, dump=None):
             """W untimed + K timed frames with generator `mode`: (renderer, whole-job seconds, kernel seconds), max over ranks."""
             rend = pt.Renderer(WIDTH, HEIGHT, spp, rng_mode=mode, row_begin=rb, row_end=re_, variant=None if fast_math else args.variant,
                                persist_rng=True, fast_math=fast_math, max_bounces=MAXB)
@@ -372,19 +375,32 @@ def main():
                 step(events[k])
             sync()
             dt = time.perf_counter() - t0
+            rend.check()  # an enqueued frame whose sample-chunk chain broke is an error of this run, not of nobody
             k_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-            tmax = torch.tensor([dt, k_ms / 1e3], dtype=torch.float64, device=device)
+            # ONE frame on its own (N > 1): render, then the gather, nothing overlapped -- the latency a caller of the synchronous
+            # Renderer::Render sees ("ms/frame incl. RCCL gather"), next to the pipelined ms_per_step above
+            if dump and rank == 0:  # the last TIMED frame (the latency frame below would be one frame further on)
+                import numpy as np
+
+                np.save(dump, fgs[(step_no[0] - 1) % len(fgs)].frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
+            lat = 0.0
+            if world > 1:
+                sync()
+                t1 = time.perf_counter()
+                step()
+                sync()
+                lat = time.perf_counter() - t1
+            tmax = torch.tensor([dt, k_ms / 1e3, lat], dtype=torch.float64, device=device)
             if use_dist:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            single_frame[0] = tmax[2].item()
             return rend, tmax[0].item(), tmax[1].item()
 
-        renderer, elapsed, kernel_s = measure(rng_mode)
+        single_frame = [0.0]
+        renderer, elapsed, kernel_s = measure(rng_mode, dump=args.dump)
+        latency = {"frame_latency_ms": round(single_frame[0] * 1e3, 3),
+                   "exchange_exposed_ms": round(max(single_frame[0] - kernel_s, 0.0) * 1e3, 3)} if world > 1 else None
         ki = renderer.kernel_info(len(spheres))
-        main_last_slot = (step_no[0] - 1) % len(fgs)
-        if rank == 0 and args.dump:
-            import numpy as np
-
-            np.save(args.dump, fgs[main_last_slot].frame.cpu().numpy().reshape(HEIGHT, WIDTH, 14))
         # the same measurement with the counter-based generator (north star: "a counter-based RNG in registers
         # replacing curand"); reported beside the headline, which stays on the reference's XORWOW stream
         alt = None
@@ -481,6 +497,8 @@ def main():
             "other_configs": others,
             "kernel_info": dict(ki, fingerprint=pt.build_fingerprint()),
         }
+        if latency:  # N > 1: one unpipelined frame (render + gather) and what the gather adds to the slowest rank's kernel
+            out.update(latency)
         if n_gpus == 1 and not native and not args.no_cpu_baseline:
             oracle = ge.load_oracle()
             oracle.build()

@@ -69,7 +69,7 @@ class MgpuOpts(ctypes.Structure):
         ("gather", ctypes.c_int32),
         ("force_exchange", ctypes.c_int32),
         ("timeout_ms", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("bands", ctypes.c_int32),
     ]
 
 
@@ -122,6 +122,7 @@ ABI = {
     "pt_mgpu_tile": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                     ctypes.POINTER(ctypes.c_int), _fp]),
     "pt_mgpu_backend": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "pt_mgpu_frame_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _fp, _fp]),
     "pt_scene_cornell": (ctypes.c_int, [_vp]),
     "pt_scene_random": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _vp]),
     "pt_camera_basis": (ctypes.c_int, [_fp, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp]),
@@ -409,7 +410,7 @@ class MultiRenderer:
     device inside the library, RCCL or peer-copy exchange to devices[0])."""
 
     def __init__(self, devices, width, height, spp, threads_per_block=8, *, max_bounces=5, rng_mode=RNG_XORWOW, seed=0,
-                 persist_rng=True, variant=None, gather=None, force_exchange=None, timeout_ms=None, fast_math=False):
+                 persist_rng=True, variant=None, gather=None, force_exchange=None, timeout_ms=None, fast_math=False, bands=None):
         o = RendererOpts()
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.max_bounces, o.rng_mode, o.seed = max_bounces, rng_mode, seed
@@ -425,6 +426,8 @@ class MultiRenderer:
             mo.force_exchange = 1 if force_exchange else 0
         if timeout_ms is not None:
             mo.timeout_ms = timeout_ms
+        if bands is not None:
+            mo.bands = bands  # 0 automatic, n row bands per tile (pipelined exchange)
         devs = (ctypes.c_int * len(devices))(*devices)
         h = _vp()
         check(lib.pt_mgpu_create(len(devices), devs, width, height, spp, threads_per_block, ctypes.byref(o), ctypes.byref(mo), ctypes.byref(h)))
@@ -443,6 +446,12 @@ class MultiRenderer:
         dev, rb, re_, ms = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0)
         check(lib.pt_mgpu_tile(self.handle, rank, ctypes.byref(dev), ctypes.byref(rb), ctypes.byref(re_), ctypes.byref(ms)))
         return {"rank": rank, "device": dev.value, "rows": (rb.value, re_.value), "kernel_ms": ms.value}
+
+    def frame_stats(self):
+        """Last frame: bands per tile, the longest rank's render ms, and what the exchange added on top (wall - render)."""
+        b, r, x = ctypes.c_int(0), ctypes.c_float(0), ctypes.c_float(0)
+        check(lib.pt_mgpu_frame_stats(self.handle, ctypes.byref(b), ctypes.byref(r), ctypes.byref(x)))
+        return {"bands": b.value, "render_ms": r.value, "exposed_ms": x.value}
 
     def backend(self):
         buf = ctypes.create_string_buffer(128)

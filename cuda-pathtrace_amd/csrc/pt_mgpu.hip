@@ -13,6 +13,9 @@
 //   placement and ragged tiles.  The G-1 transfers arrive over G-1 distinct xGMI links (a gather, not a ring:
 //   the per-link ring bound does not apply).
 // RCCL is loaded with dlopen on first use, so the single-GPU path of libptcore.so does not depend on it.
+// Round 4: the exchange is pipelined INSIDE a frame.  A rank renders its tile as row bands (one launch each, one renderer each)
+// and band b's send -- the root: band b's receives -- is posted on a second stream behind band b's kernel, so it travels while
+// band b + 1 renders; only the last band's transfer is exposed.  Renderer::Render stays synchronous (include/Renderer.h:55-76).
 // A second exchange backend, peer copies on the tile's stream (hipMemcpyPeerAsync: the SDMA engines move
 // the tile over the same xGMI link, no CU involved), serves two ranks sharing one device (RCCL refuses
 // duplicate devices in one communicator) and is selectable for A/B.
@@ -105,9 +108,14 @@ struct Job {  // one frame; filled by pt_mgpu_render, read by every worker
 struct pt_mgpu {
   struct Rank {
     int rank = 0, device = 0, row_begin = 0, row_end = 0;
-    pt_renderer* renderer = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around this rank's kernel
+    // The tile is rendered as `bands` row bands, one renderer each (a renderer owns the generator state and the scratch of its
+    // rows), launched back to back on `stream`; band b's part of the exchange is posted on `xfer` behind an event, so it travels
+    // while band b + 1 renders and only the LAST band's transfer is exposed.  One band: one stream, as before round 4.
+    std::vector<pt_renderer*> band;
+    std::vector<int> band_begin;               // first row of band b (band_begin[bands] = row_end)
+    std::vector<hipEvent_t> ev_band;           // band b has been rendered
+    hipStream_t stream = nullptr, xfer = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around this rank's kernels
     float* d_tile = nullptr;                   // rendered here unless the tile is rendered in place
     pt_sphere* d_scene = nullptr;              // this device's replica of the scene (non-root)
     int scene_capacity = 0;
@@ -119,6 +127,9 @@ struct pt_mgpu {
     float kernel_ms = 0.0f;
   };
   int n = 0, width = 0, height = 0, spp = 0, tpb = 0;
+  int bands = 1;             // row bands per tile (the same on every rank: band b of every peer is one grouped exchange step)
+  float exposed_ms = 0.0f;   // last frame: wall time minus the longest rank's render time
+  float render_ms = 0.0f;    // last frame: the longest rank's render time (first launch to last band done)
   pt_renderer_opts ropts;
   pt_mgpu_opts opts;
   bool use_rccl = false;
@@ -175,15 +186,26 @@ bool in_place(const pt_mgpu* m, const pt_mgpu::Rank& rk) {
 void worker_init(pt_mgpu* m, pt_mgpu::Rank& rk) {
   W_HIP(hipSetDevice(rk.device));
   W_HIP(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
+  if (m->bands > 1) W_HIP(hipStreamCreateWithFlags(&rk.xfer, hipStreamNonBlocking));
   W_HIP(hipEventCreate(&rk.ev0));
   W_HIP(hipEventCreate(&rk.ev1));
-  pt_renderer_opts o = m->ropts;
-  o.row_begin = rk.row_begin;
-  o.row_end = rk.row_end;
-  if (rk.row_end > rk.row_begin) {
-    W_PT(pt_renderer_create(m->width, m->height, m->spp, m->tpb, &o, &rk.renderer));
-    if (!in_place(m, rk)) W_HIP(hipMalloc((void**)&rk.d_tile, (size_t)(rk.row_end - rk.row_begin) * m->width * 14 * sizeof(float)));
+  const int rows = rk.row_end - rk.row_begin;
+  rk.band_begin.assign(m->bands + 1, rk.row_end);
+  for (int b = 0; b < m->bands; b++) {
+    int lo, hi;
+    row_range(rows, m->bands, b, &lo, &hi);  // ragged like the tiles themselves; a tile of fewer rows than bands has empty ones
+    rk.band_begin[b] = rk.row_begin + lo;
   }
+  rk.band.assign(m->bands, nullptr);
+  rk.ev_band.assign(m->bands, nullptr);
+  for (int b = 0; b < m->bands; b++) {
+    if (m->bands > 1) W_HIP(hipEventCreateWithFlags(&rk.ev_band[b], hipEventDisableTiming));
+    pt_renderer_opts o = m->ropts;
+    o.row_begin = rk.band_begin[b];
+    o.row_end = rk.band_begin[b + 1];
+    if (o.row_end > o.row_begin) W_PT(pt_renderer_create(m->width, m->height, m->spp, m->tpb, &o, &rk.band[b]));
+  }
+  if (rows > 0 && !in_place(m, rk)) W_HIP(hipMalloc((void**)&rk.d_tile, (size_t)rows * m->width * 14 * sizeof(float)));
 }
 
 #if PT_BUILD_EXPERIMENTS
@@ -244,49 +266,61 @@ void worker_frame(pt_mgpu* m, pt_mgpu::Rank& rk) {
     scene = rk.d_scene;
   }
   float* target = in_place(m, rk) ? j.d_out + (size_t)rk.row_begin * row_floats : rk.d_tile;
-  bool timed = false;
-  if (count && scene_ok) {
-    timed = note_hip(hipEventRecord(rk.ev0, rk.stream), "hipEventRecord");
-    note_pt(pt_renderer_enqueue(rk.renderer, target, scene, j.n_spheres, j.basis, j.eye, rk.stream));
-    timed = note_hip(hipEventRecord(rk.ev1, rk.stream), "hipEventRecord") && timed;
-  }
+  hipStream_t xs = m->bands > 1 ? rk.xfer : rk.stream;  // where the exchange is posted
+  bool timed = false, comm_broken = false;
+  if (count && scene_ok) timed = note_hip(hipEventRecord(rk.ev0, rk.stream), "hipEventRecord");
+  if (m->use_rccl && !rk.comm) comm_broken = true;
+  for (int b = 0; b < m->bands; b++) {
+    const int b0 = rk.band_begin[b], b1 = rk.band_begin[b + 1];
+    const size_t bcount = (size_t)(b1 - b0) * row_floats, boff = (size_t)(b0 - rk.row_begin) * row_floats;
+    // ---- render band b ----
+    bool rendered = false;
+    if (bcount && scene_ok && rk.band[b])
+      rendered = note_pt(pt_renderer_enqueue(rk.band[b], target + boff, scene, j.n_spheres, j.basis, j.eye, rk.stream));
+    (void)rendered;
 #if PT_BUILD_EXPERIMENTS
-  if (const char* st = getenv("PT_LAB_MGPU_STALL")) {
-    int r = -1, ms = 0;
-    if (sscanf(st, "%d:%d", &r, &ms) == 2 && r == rk.rank && ms > 0)
-      note_hip(hipLaunchHostFunc(rk.stream, lab_sleep_ms, (void*)(intptr_t)ms), "hipLaunchHostFunc");
-  }
-#endif
-  // ---- the exchange step: posted even by a rank whose render failed (the frame fails, but nobody waits for it) ----------
-  bool comm_broken = false;
-  if (m->use_rccl) {
-    if (!rk.comm) {
-      comm_broken = true;
-    } else if (note_nccl(m->rccl->GroupStart(), "ncclGroupStart")) {
-      if (rk.rank == 0) {
-        for (const pt_mgpu::Rank& p : m->ranks) {
-          const size_t pc = (size_t)(p.row_end - p.row_begin) * row_floats;
-          if (pc && !in_place(m, p))
-            comm_broken |= !note_nccl(m->rccl->Recv(j.d_out + (size_t)p.row_begin * row_floats, pc, ncclFloat, p.rank, rk.comm, rk.stream), "ncclRecv");
-        }
+    if (b == m->bands - 1)
+      if (const char* st = getenv("PT_LAB_MGPU_STALL")) {
+        int r = -1, ms = 0;
+        if (sscanf(st, "%d:%d", &r, &ms) == 2 && r == rk.rank && ms > 0)
+          note_hip(hipLaunchHostFunc(rk.stream, lab_sleep_ms, (void*)(intptr_t)ms), "hipLaunchHostFunc");
       }
-      if (count && !in_place(m, rk)) comm_broken |= !note_nccl(m->rccl->Send(rk.d_tile, count, ncclFloat, 0, rk.comm, rk.stream), "ncclSend");
-      comm_broken |= !note_nccl(m->rccl->GroupEnd(), "ncclGroupEnd");  // a started group is always ended
-    } else {
-      comm_broken = true;
+#endif
+    if (m->bands > 1) {  // band b's exchange waits for band b's kernel only
+      note_hip(hipEventRecord(rk.ev_band[b], rk.stream), "hipEventRecord");
+      note_hip(hipStreamWaitEvent(xs, rk.ev_band[b], 0), "hipStreamWaitEvent");
     }
-    if (comm_broken && rk.comm) {  // peers may be waiting for operations this rank could not post: unblock them
-      (void)m->rccl->CommAbort(rk.comm);
-      rk.comm = nullptr;
+    // ---- band b's exchange step: posted even by a rank whose render failed (the frame fails, but nobody waits for it) -----
+    if (m->use_rccl) {
+      if (comm_broken) continue;
+      if (note_nccl(m->rccl->GroupStart(), "ncclGroupStart")) {
+        if (rk.rank == 0) {
+          for (const pt_mgpu::Rank& p : m->ranks) {
+            const size_t pc = (size_t)(p.band_begin[b + 1] - p.band_begin[b]) * row_floats;
+            if (pc && !in_place(m, p))
+              comm_broken |= !note_nccl(m->rccl->Recv(j.d_out + (size_t)p.band_begin[b] * row_floats, pc, ncclFloat, p.rank, rk.comm, xs), "ncclRecv");
+          }
+        }
+        if (bcount && !in_place(m, rk)) comm_broken |= !note_nccl(m->rccl->Send(rk.d_tile + boff, bcount, ncclFloat, 0, rk.comm, xs), "ncclSend");
+        comm_broken |= !note_nccl(m->rccl->GroupEnd(), "ncclGroupEnd");  // a started group is always ended
+      } else {
+        comm_broken = true;
+      }
+    } else if (bcount && !in_place(m, rk)) {
+      note_hip(hipMemcpyPeerAsync(j.d_out + (size_t)b0 * row_floats, root.device, rk.d_tile + boff, rk.device, bcount * sizeof(float), xs),
+               "hipMemcpyPeerAsync(band)");
     }
-  } else if (count && !in_place(m, rk)) {
-    note_hip(hipMemcpyPeerAsync(j.d_out + (size_t)rk.row_begin * row_floats, root.device, rk.d_tile, rk.device, count * sizeof(float), rk.stream),
-             "hipMemcpyPeerAsync(tile)");
+  }
+  if (count && scene_ok) timed = note_hip(hipEventRecord(rk.ev1, rk.stream), "hipEventRecord") && timed;
+  if (m->use_rccl && comm_broken && rk.comm) {  // peers may be waiting for operations this rank could not post: unblock them
+    (void)m->rccl->CommAbort(rk.comm);
+    rk.comm = nullptr;
   }
   // ---- completion, with a deadline: a peer that never arrives must not hang the caller ----------------
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->opts.timeout_ms);
   for (;;) {
-    const hipError_t q = hipStreamQuery(rk.stream);
+    hipError_t q = hipStreamQuery(rk.stream);
+    if (q == hipSuccess && m->bands > 1) q = hipStreamQuery(rk.xfer);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) {
       note_hip(q, "hipStreamQuery");
@@ -306,7 +340,8 @@ void worker_frame(pt_mgpu* m, pt_mgpu::Rank& rk) {
     std::this_thread::sleep_for(std::chrono::microseconds(20));  // a frame is >= milliseconds; do not burn a core per rank
   }
   // the stream has drained: a frame whose sample-chunk chain broke belongs to THIS call, not to the next one (or to nobody)
-  if (count) note_pt(pt_renderer_check(rk.renderer, 1, nullptr));
+  for (pt_renderer* r : rk.band)
+    if (r) note_pt(pt_renderer_check(r, 1, nullptr));
   if (timed && first_rc == PT_OK) note_hip(hipEventElapsedTime(&rk.kernel_ms, rk.ev0, rk.ev1), "hipEventElapsedTime");
   rk.rc = first_rc;
 }
@@ -333,7 +368,11 @@ void worker_main(pt_mgpu* m, int index) {
   }
   // teardown on the owning thread (the device binding is per thread)
   (void)hipSetDevice(rk.device);
-  if (rk.renderer) (void)pt_renderer_destroy(rk.renderer);
+  for (pt_renderer* r : rk.band)
+    if (r) (void)pt_renderer_destroy(r);
+  for (hipEvent_t e : rk.ev_band)
+    if (e) (void)hipEventDestroy(e);
+  if (rk.xfer) (void)hipStreamDestroy(rk.xfer);
   if (rk.d_tile) (void)hipFree(rk.d_tile);
   if (rk.d_scene) (void)hipFree(rk.d_scene);
   if (rk.ev0) (void)hipEventDestroy(rk.ev0);
@@ -373,6 +412,7 @@ void pt_mgpu_opts_default(pt_mgpu_opts* o) {
   o->gather = PT_GATHER_AUTO;
   o->force_exchange = env_int("PT_FORCE_MGPU", 0) ? 1 : 0;
   o->timeout_ms = env_int("PT_MGPU_TIMEOUT_MS", 60000);
+  o->bands = env_int("PT_MGPU_BANDS", 0);
   const char* g = getenv("PT_MGPU_GATHER");
   if (g && !strcmp(g, "rccl")) o->gather = PT_GATHER_RCCL;
   if (g && !strcmp(g, "copy")) o->gather = PT_GATHER_PEER_COPY;
@@ -422,6 +462,31 @@ int pt_mgpu_create(int n_gpus, const int* devices, int width, int height, int sa
     return pt_fail(PT_EINVAL, "pt_mgpu_create: PT_GATHER_RCCL needs distinct devices");
   }
   m->use_rccl = anything_to_exchange && (m->opts.gather == PT_GATHER_RCCL || (m->opts.gather == PT_GATHER_AUTO && !duplicates));
+  // Row bands per tile.  A band must still fill the chip -- at least eight one-lane waves per SIMD (BASELINE configs[2]: a
+  // rank's 512 x 4096 tile = 32 waves per SIMD -> 4 bands of 128 rows; configs[1]: a rank's tile is 2 waves per SIMD -> 1 band,
+  // and its 7 MB are not worth hiding) -- and there is nothing to hide unless a tile crosses a link: an exchange between ranks
+  // that share the root's device is an on-device copy at HBM speed (117 MB in 0.05-0.1 ms), against which four launches instead
+  // of one cost the render 2 % (profiles/r04/mgpu_bands.txt).  opts.bands > 0 bands whatever the devices are.
+  if (m->opts.bands < 0 || m->opts.bands > 64) {
+    const int bad = m->opts.bands;
+    delete m;
+    return pt_fail(PT_EINVAL, "pt_mgpu_create: bands %d (0 = automatic, 1..64)", bad);
+  }
+  m->bands = 1;
+  if (anything_to_exchange) {
+    if (m->opts.bands > 0) {
+      m->bands = m->opts.bands;
+    } else {
+      bool crosses_link = false;
+      for (const pt_mgpu::Rank& rk : m->ranks) crosses_link |= rk.device != m->ranks[0].device;
+      hipDeviceProp_t prop;
+      if (crosses_link && hipGetDeviceProperties(&prop, m->ranks[0].device) == hipSuccess && prop.multiProcessorCount > 0) {
+        const double tile_pixels = (double)(m->ranks[0].row_end - m->ranks[0].row_begin) * width;
+        const int b = (int)(tile_pixels / ((double)prop.multiProcessorCount * 4.0 * 64.0) / 8.0);
+        m->bands = b < 1 ? 1 : (b > 8 ? 8 : b);
+      }
+    }
+  }
   if (m->use_rccl) {
     m->rccl = load_rccl();
     if (!m->rccl->error.empty()) {
@@ -489,8 +554,20 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
   // unusable from here on if ANY rank timed out or has aborted its communicator, whichever rank's error is reported
   for (const pt_mgpu::Rank& rk : m->ranks)
     if (rk.rc == PT_ETIMEOUT || (m->use_rccl && !rk.comm)) m->failed = true;
-  if (ms_out) *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms_out) *ms_out = wall;
+  m->render_ms = 0.0f;
+  for (const pt_mgpu::Rank& rk : m->ranks) m->render_ms = rk.kernel_ms > m->render_ms ? rk.kernel_ms : m->render_ms;
+  m->exposed_ms = wall > m->render_ms ? wall - m->render_ms : 0.0f;
   return rc;
+}
+
+int pt_mgpu_frame_stats(pt_mgpu* m, int* bands, float* render_ms, float* exposed_ms) {
+  if (!m) return pt_fail(PT_EINVAL, "pt_mgpu_frame_stats: handle is NULL");
+  if (bands) *bands = m->bands;
+  if (render_ms) *render_ms = m->render_ms;
+  if (exposed_ms) *exposed_ms = m->exposed_ms;
+  return PT_OK;
 }
 
 int pt_mgpu_tile(pt_mgpu* m, int rank, int* device, int* row_begin, int* row_end, float* kernel_ms) {

@@ -202,11 +202,14 @@ typedef struct pt_mgpu_opts {
                            /*    multi-GPU path on a single-GPU machine.  Env PT_FORCE_MGPU=1.      */
   int32_t timeout_ms;      /* a frame not complete after this long fails with PT_ETIMEOUT and the  */
                            /*    communicator is aborted (0 = wait forever).  Env PT_MGPU_TIMEOUT_MS, default 60000 */
-  int32_t reserved;
+  int32_t bands;           /* row bands a rank's tile is rendered in: band b's transfer overlaps band b+1's   */
+                           /*    kernel, only the last band's is exposed.  0 = automatic (bands of at least    */
+                           /*    eight one-lane waves per SIMD, at most 8; 1 when no tile crosses a link), 1..64. */
+                           /*    Env PT_MGPU_BANDS.  Same bits whatever the value.                               */
 } pt_mgpu_opts;
 typedef struct pt_mgpu pt_mgpu; /* opaque */
 
-/* Defaults, with the environment overrides PT_FORCE_MGPU, PT_MGPU_TIMEOUT_MS, PT_MGPU_GATHER=rccl|copy. */
+/* Defaults, with the environment overrides PT_FORCE_MGPU, PT_MGPU_TIMEOUT_MS, PT_MGPU_GATHER=rccl|copy, PT_MGPU_BANDS. */
 void pt_mgpu_opts_default(pt_mgpu_opts* opts);
 /* Renderer::Renderer over n_gpus devices (devices == NULL: 0..n_gpus-1; devices[0] is the root that
  * owns the caller's frame and scene).  opts as for pt_renderer_create, with row_begin = row_end = 0;
@@ -229,6 +232,9 @@ int pt_mgpu_render(pt_mgpu* m, float* d_out, const pt_sphere* d_spheres, int n_s
                    const float basis[12], const float eye[3], float* ms_out);
 /* Row block, device and last kernel time of a rank (any out pointer may be NULL). */
 int pt_mgpu_tile(pt_mgpu* m, int rank, int* device, int* row_begin, int* row_end, float* kernel_ms);
+/* Timing of the last pt_mgpu_render (any out pointer may be NULL): bands per tile, the longest rank's render time (first
+ * launch to last band done, hipEvent pair) and what the exchange added on top of it (end-to-end wall time minus that). */
+int pt_mgpu_frame_stats(pt_mgpu* m, int* bands, float* render_ms, float* exposed_ms);
 /* Name of the exchange backend in use (for logs / bench). */
 int pt_mgpu_backend(pt_mgpu* m, char* name, size_t name_len);
 

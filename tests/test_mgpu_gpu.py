@@ -81,6 +81,58 @@ def test_rccl_exchange_on_one_gpu_self_send_recv(pt, oracle, gpu):
     assert_bit_exact(frames[0], oracle.render(48, 48, 2, spheres=scene, basis=pt.camera_basis(width=48, height=48)), "rccl, 400 spheres")
 
 
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+@pytest.mark.parametrize("backend", ["copy", "rccl"])
+def test_banded_tiles_pipeline_the_exchange_inside_a_frame(pt, oracle, gpu, rng, backend):
+    """Round 4: a rank renders its tile as row bands and band b's part of the exchange travels while band b + 1 renders
+    (include/ptcore.h, pt_mgpu_opts.bands).  Ragged bands (3 ranks x 3 bands over 100 rows: 34 -> 12/11/11, 33 -> 11/11/11),
+    more bands than a tile has rows, two frames with the generator state of every band carried over, both generators, the
+    peer-copy exchange between ranks sharing the device and the RCCL exchange (one-rank communicator, self send/recv per band):
+    the frame may not change by a bit."""
+    size, spp = 100, 4
+    basis = pt.camera_basis(width=size, height=size)
+    if backend == "copy":
+        cases = [([0, 0, 0], dict(bands=3, force_exchange=True)), ([0, 0], dict(bands=64, force_exchange=True)), ([0, 0, 0], dict(bands=5))]
+    else:
+        cases = [([0], dict(bands=4, force_exchange=True, gather=pt.GATHER_RCCL, timeout_ms=30000))]
+    for devices, kw in cases:
+        frames, info = _render_mgpu(pt, devices, size, spp, frames=2, rng_mode=rng, **kw)
+        assert info["backend"].startswith("rccl" if backend == "rccl" else "hipMemcpyPeerAsync")
+        st = oracle.setup_random(size, size) if rng == 0 else None
+        for f, img in enumerate(frames):
+            ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng, rng_state=st, frame=f)
+            assert_bit_exact(img, ref, f"{len(devices)} ranks, {kw}, frame {f}")
+
+
+def test_band_policy_and_frame_stats(pt, gpu):
+    """Automatic bands: none unless a tile crosses a link (ranks sharing the root's device exchange at HBM speed); between distinct
+    devices, bands of at least eight one-lane waves per SIMD (BASELINE configs[2]: 512 x 4096 -> 4 bands; configs[1]'s tiles of 2
+    waves per SIMD: 1).  pt_mgpu_frame_stats reports them with the render / exposed-exchange split of the last frame."""
+    m = pt.MultiRenderer([0], 64, 64, 1)
+    assert m.frame_stats()["bands"] == 1
+    m.destroy()
+    m = pt.MultiRenderer([0], 4096, 512, 1, force_exchange=True)
+    assert m.frame_stats()["bands"] == 1
+    m.destroy()
+    if pt.device_count() >= 2:
+        m = pt.MultiRenderer([0, 1], 4096, 1024, 1)
+        assert m.frame_stats()["bands"] == 4
+        m.destroy()
+        m = pt.MultiRenderer([0, 1], 1024, 256, 1)
+        assert m.frame_stats()["bands"] == 1
+        m.destroy()
+    m = pt.MultiRenderer([0], 4096, 512, 1, force_exchange=True, bands=4)
+    assert m.frame_stats()["bands"] == 4
+    d_scene, n = pt.upload_scene(pt.scene_cornell())
+    d_out = pt.DeviceBuffer(4096 * 512 * 56)
+    ms = m.render(d_out.ptr, d_scene.ptr, n, pt.camera_basis(width=4096, height=512))
+    fs = m.frame_stats()
+    assert fs["render_ms"] > 0 and 0 <= fs["exposed_ms"] <= ms and abs(fs["render_ms"] + fs["exposed_ms"] - ms) < 1e-3 * ms + 1e-3
+    m.destroy()
+    with pytest.raises(pt.PtError):
+        pt.MultiRenderer([0], 16, 16, 1, bands=65)
+
+
 def test_real_multi_gpu_rccl_gather(pt, oracle, gpu):
     """Distinct devices, RCCL over xGMI: only where the box has them (the driver's test box has one GPU)."""
     n = pt.device_count()
