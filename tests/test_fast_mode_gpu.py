@@ -14,7 +14,9 @@ written here:
       (SURVEY.md fact 5).  The share grows with spp (one divergent path in a pixel is enough: 6.6 % at 256 spp, 23 % at
       1024 spp) while each divergent path weighs 1/spp;
   T4  the row-tile independence and the generator-state persistence of the exact kernels hold bit for bit
-      (fast mode against fast mode)."""
+      (fast mode against fast mode);
+  T5  the distance from the ORACLE (the reference's CPU restatement) per channel at 256 x 256 x {1, 64} spp: the table the
+      tolerances in include/ptcore.h quote (round 4)."""
 import numpy as np
 import pytest
 
@@ -71,6 +73,66 @@ def test_t3_pixelwise_divergence_is_bounded(pt, gpu):
     # first-hit features are averaged over jittered samples, far less chaotic: 99 % of pixels within 1e-4 (normals)
     nd = np.abs(exact[..., 3:6] - fast[..., 3:6]).max(axis=-1)
     assert (nd > 1e-4).mean() <= 0.01
+
+
+_CHANNELS = [("colour", (0, 1, 2), False), ("normal", (3, 4, 5), False), ("albedo", (6, 7, 8), False), ("depth", (9,), True),
+             ("colourVar", (10,), False), ("normalVar", (11,), False), ("albedoVar", (12,), False), ("depthVar", (13,), True)]
+
+
+def _distance_table(ref, fast):
+    """Per channel group: L-infinity, 99.9th percentile, median and share of pixels beyond 1e-4 (depth and its variance
+    RELATIVE: depth is t along the un-normalised primary direction, about 1e4)."""
+    rows = {}
+    for name, ch, rel in _CHANNELS:
+        a, b = ref[..., ch].astype(np.float64), fast[..., ch].astype(np.float64)
+        d = np.abs(a - b)
+        if rel:
+            d = d / np.maximum(np.abs(a), 1e-30)
+        d = d.max(axis=-1)
+        rows[name] = {"relative": rel, "linf": float(d.max()), "p999": float(np.quantile(d, 0.999)), "median": float(np.median(d)),
+                      "share_gt_1e-4": float((d > 1e-4).mean())}
+    return rows
+
+
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_t5_distance_from_the_oracle(pt, oracle, gpu, rng):
+    """The north star states its tolerance against the REFERENCE ("per-pixel L-inf <= 1e-4 at fixed seed"), so the fast mode is
+    measured against the reference's oracle, not only against this repository's other kernel: 256 x 256 x {1, 64} spp, equal
+    seeds.  What holds (and is quoted in include/ptcore.h):
+      1 spp  -- albedo identical in >= 99.8 % of the pixels; where it is: normals p99.9 <= 2e-4, depth p99.9 <= 5e-4 relative;
+      64 spp -- colour beyond 1e-4 in <= 3 % of the pixels (median 0), normals in <= 1 %, albedo in <= 1 %, depth p99.9 <= 5e-3
+                relative: one ray in 64 that rounds onto another surface moves a pixel by up to 1/64 of the feature's range.
+    The L-inf of the north star is NOT met by any implementation that rounds differently from the reference -- the reference's
+    own source compiled with and without FMA contraction is 0.06 apart in colour at 64 spp -- which is why
+    the headline stays on the bit-exact kernels.  PT_FAST_TABLE_OUT=<file>: the full table as JSON (profiles/r04/fast_vs_oracle.json)."""
+    import json
+    import os
+
+    size = 256
+    basis = pt.camera_basis(width=size, height=size)
+    record = {"fingerprint": pt.build_fingerprint(), "size": size, "rng": ["xorwow", "philox"][rng], "cases": []}
+    for spp in (1, 64):
+        ref = oracle.render(size, size, spp, spheres=pt.scene_cornell(), basis=basis, rng_mode=rng)
+        fast, _ = pt.render_frame(size, size, spp, basis=basis, rng_mode=rng, fast_math=True)
+        assert np.isfinite(fast).all()
+        same = np.all(ref[..., 6:9] == fast[..., 6:9], axis=-1)
+        t = _distance_table(ref, fast)
+        record["cases"].append({"spp": spp, "albedo_identical_share": float(same.mean()), "channels": t})
+        print(f"{record['rng']} {spp} spp: albedo identical {same.mean():.4f}; " +
+              "; ".join(f"{k} Linf {v['linf']:.3g} p99.9 {v['p999']:.3g} >1e-4 {100 * v['share_gt_1e-4']:.3f}%" for k, v in t.items()))
+        if spp == 1:
+            assert same.mean() >= 0.998
+            ts = _distance_table(ref[same][None], fast[same][None])
+            assert ts["normal"]["p999"] <= 2e-4 and ts["depth"]["p999"] <= 5e-4
+            assert all(t[k]["linf"] == 0.0 for k in ("colourVar", "normalVar", "albedoVar", "depthVar"))
+        else:
+            assert t["colour"]["share_gt_1e-4"] <= 0.03 and t["colour"]["median"] <= 1e-6
+            assert t["normal"]["share_gt_1e-4"] <= 0.01 and t["albedo"]["share_gt_1e-4"] <= 0.01
+            assert t["depth"]["p999"] <= 5e-3
+    out = os.environ.get("PT_FAST_TABLE_OUT")
+    if out:
+        prev = json.load(open(out)) if os.path.exists(out) else []
+        json.dump([r for r in prev if r.get("rng") != record["rng"]] + [record], open(out, "w"), indent=1)
 
 
 def test_t4_tiles_and_generator_state(pt, gpu):

@@ -4,9 +4,10 @@
 # Usage: tools/refresh_profiles.sh [round=r02]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r03}
+R=${1:-r04}
 python3 tools/summarise_profile.py cfg2_xorwow $R > /dev/null
 python3 tools/summarise_profile.py cfg2_philox $R > /dev/null
+python3 tools/summarise_profile.py cfg2_fast $R > /dev/null
 python3 tools/summarise_profile.py cfg4_v13_closed $R > /dev/null
 python3 tools/summarise_profile.py cfg4_v13_open $R > /dev/null
 python3 tools/summarise_profile.py cfg4_v11_closed $R > /dev/null
@@ -15,6 +16,7 @@ python3 tools/summarise_profile.py cfg3_xorwow $R > /dev/null
 rm -f profiles/hbm_traffic.json profiles/valu_roofline.json
 python3 tools/update_roofline_json.py cfg2_xorwow $R cfg2_xorwow_v6
 python3 tools/update_roofline_json.py cfg2_philox $R cfg2_philox_v6
+python3 tools/update_roofline_json.py cfg2_fast $R cfg2_xorwow_v100
 python3 tools/update_roofline_json.py cfg3_xorwow $R cfg3_xorwow_v6
 bash tools/isa.sh /tmp/pt_kernel_final.s
 python3 tools/issue_model.py /tmp/pt_kernel_final.s pixel_kernelILi0ELi6ELb0ELi5E profiles/$R/cfg2_xorwow.json cfg2_xorwow_v6 | cut -c1-400
