@@ -109,6 +109,7 @@ ABI = {
     "pt_renderer_render": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _fp]),
     "pt_renderer_enqueue": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _vp]),
     "pt_renderer_check": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_renderer_set_display": (ctypes.c_int, [_vp, _vp]),
     "pt_renderer_set_frame": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "pt_renderer_reset_rng": (ctypes.c_int, [_vp]),
     "pt_renderer_get_rng_state": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
@@ -372,6 +373,10 @@ class Renderer:
         n = ctypes.c_uint32(0)
         check(lib.pt_renderer_check(self.handle, 1 if wait else 0, ctypes.byref(n)))
         return n.value
+
+    def set_display(self, d_vertices):
+        """Every frame also writes the display vertices (Denoiser::Denoise fused into the render); None switches it off."""
+        check(lib.pt_renderer_set_display(self.handle, d_vertices))
 
     def set_frame(self, frame):
         check(lib.pt_renderer_set_frame(self.handle, frame))

@@ -62,6 +62,7 @@ struct pt_renderer {
   uint64_t chunk_wait_ticks;  // how long a chunk waits for its predecessor (wall-clock ticks of the device)
   long chunk_wait_ms;         // ... the same in milliseconds (env PT_CHUNK_TIMEOUT_MS, default 4000)
   uint32_t repaired;          // frames whose broken chunk chain pt_renderer_render repaired (pt_renderer_check reports it)
+  float* d_vertices;          // pt_renderer_set_display: the display vertices every frame also writes, or null
   uint32_t* d_err;         // device error word (PT_DEVERR_*), raised by a kernel that could not go on correctly
   uint32_t* h_err;         // pinned host copy, valid once ev_err has completed
   hipEvent_t ev_err;
@@ -328,6 +329,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->chunk_wait_ticks = 0;
   r->chunk_wait_ms = 0;
   r->repaired = 0;
+  r->d_vertices = nullptr;
   r->d_err = nullptr;
   r->h_err = nullptr;
   r->ev_err = nullptr;
@@ -539,6 +541,7 @@ static int fill_args(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, i
   a->chunk_wait_ticks = r->chunk_wait_ticks;
   a->debug = r->debug;
   a->repair = 0u;
+  a->vertices = r->d_vertices;
   return PT_OK;
 }
 
@@ -650,6 +653,12 @@ int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames) {
   if (!r) return pt_fail(PT_EINVAL, "pt_renderer_check: renderer is NULL");
   if (repaired_frames) *repaired_frames = r->repaired;
   return check_device_error(r, wait != 0);
+}
+
+int pt_renderer_set_display(pt_renderer* r, float* d_vertices) {
+  if (!r) return pt_fail(PT_EINVAL, "pt_renderer_set_display: renderer is NULL");
+  r->d_vertices = d_vertices;
+  return PT_OK;
 }
 
 int pt_renderer_set_frame(pt_renderer* r, uint32_t frame) {

@@ -677,4 +677,21 @@ __device__ __forceinline__ F3 cosine_weighted_fast(F3 dir, float u_az, float u_e
   return (a + b) + c;
 }
 
+// denoise_kernel (src/denoise.cu:9-29, behind Denoiser::Denoise, main.cu:175) fused into the frame's epilogue: the pixel's display
+// vertex (col, width - row, colour clamped to [0, 1] and packed as uchar4 {r, g, b, 1} into one float), from the very floats the
+// frame store writes -- what pt_display_pack computes from the stored frame (pt_display.hip), without the second launch and the
+// 12 B per pixel it reads back.
+__device__ __forceinline__ void store_display_vertex(float* __restrict__ v, int width, int row, int col, float r, float g, float b) {
+  const float c[3] = {r, g, b};
+  uint32_t packed = 1u << 24;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float x = fminf(fmaxf(c[k], 0.0f), 1.0f);                         // denoise.cu:18-20
+    packed |= (uint32_t)(unsigned char)((double)x * 255.0) << (8 * k);      // :23
+  }
+  v[0] = (float)col;            // :26
+  v[1] = (float)(width - row);  // :27
+  v[2] = __uint_as_float(packed);  // :28
+}
+
 }  // namespace pt

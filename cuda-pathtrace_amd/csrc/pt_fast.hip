@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS, PT_FAST_MIN_WAVES) pixel_ker
   const float rs = __builtin_amdgcn_rcpf((float)a.spp);  // :234-237
   const float px[14] = {Lc.x * rs, Lc.y * rs, Lc.z * rs, Ln.x * rs, Ln.y * rs, Ln.z * rs, La.x * rs, La.y * rs, La.z * rs, Ld * rs,
                         var_value(var[0]), var_value(var[1]), var_value(var[2]), var_value(var[3])};
+  if (a.vertices && active) store_display_vertex(a.vertices + (size_t)tp * 3, a.width, row, col, px[0], px[1], px[2]);
   if (a.planar) {
     if (active) {
 #pragma unroll

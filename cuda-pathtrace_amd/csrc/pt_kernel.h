@@ -116,6 +116,8 @@ struct PixelKernelArgs {
   uint64_t chunk_wait_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) a chunk waits for its predecessor before it gives up
   uint32_t debug;              // lab library only (PT_DEBUG_*): deliberate faults for the failure-path tests
   uint32_t prio;               // 1: one-lane-per-pixel waves set their issue priority by progress (filled in by the launcher)
+  float* vertices;             // non-null: the frame's display vertices as well -- denoise_kernel's (col, width - row, RGBA8 packed in a
+                               // float) per pixel, [tile row][col][3], written from the registers that hold the colour (pt_renderer_set_display)
   uint32_t repair;             // != 0: repair launch after a broken chunk chain -- unchunked, and pixel blocks whose chunk_flag equals
                                // this value (= the chunk count of the broken launch: complete) are skipped
 };

@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
                         L.normal.z / fs, L.albedo.x / fs, L.albedo.y / fs, L.albedo.z / fs, L.depth / fs,
                         welford_variance(var[0]), welford_variance(var[1]), welford_variance(var[2]),
                         welford_variance(var[3])};  // :240-254
+  if (a.vertices && active) store_display_vertex(a.vertices + (size_t)tp * 3, a.width, row, col, px[0], px[1], px[2]);
   // The 64 pixels of a wave are 64 consecutive columns, so their 64 x 14 floats are ONE contiguous
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
@@ -792,9 +793,11 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS) pixel_kernel_split(PixelKern
     for (int q = 0; q < kOwn; q++) {
       const int f = s * kOwn + q;
       if (f < 3) {
-        o[(3 * f + 0) * cs] = sum0[q] / fs;
-        o[(3 * f + 1) * cs] = sum1[q] / fs;
-        o[(3 * f + 2) * cs] = sum2[q] / fs;
+        const float v0 = sum0[q] / fs, v1 = sum1[q] / fs, v2 = sum2[q] / fs;
+        o[(3 * f + 0) * cs] = v0;
+        o[(3 * f + 1) * cs] = v1;
+        o[(3 * f + 2) * cs] = v2;
+        if (f == 0 && a.vertices) store_display_vertex(a.vertices + (size_t)tp * 3, a.width, row, col, v0, v1, v2);  // the colour's owner
       } else {
         o[9 * cs] = sum0[q] / fs;
       }

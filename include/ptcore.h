@@ -166,6 +166,13 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
  * whose broken chain pt_renderer_render has repaired in place since the renderer was created (normally 0). */
 int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames);
 
+/* Renderer::Render + Denoiser::Denoise in ONE kernel (the body of the reference's interactive loop, src/main.cu:148,175):
+ * from now on every frame of this renderer also writes the display vertices denoise_kernel (src/denoise.cu:9-29) derives
+ * from it -- (col, width - row, RGBA8 {r,g,b,1} packed in a float) per pixel -- straight from the registers that hold the
+ * pixel's colour: no second launch, no 12 B per pixel read back.  d_vertices: device float [rows of this renderer][width][3],
+ * first vertex = first pixel of row_begin (like d_out); NULL switches it off.  Bit-identical to pt_display_pack(frame). */
+int pt_renderer_set_display(pt_renderer* r, float* d_vertices);
+
 /* Frame counter used by the philox key; incremented by every render/enqueue. */
 int pt_renderer_set_frame(pt_renderer* r, uint32_t frame);
 /* Re-run setup_random (pathtrace.cu:259-266): generator state as after construction. */

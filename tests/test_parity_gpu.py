@@ -601,6 +601,54 @@ def test_display_packer_matches_denoise_kernel(pt, oracle, gpu):
     assert (a[..., 2].view(np.uint32) >> 24 == 1).all()      # alpha byte = 1
 
 
+def test_fused_display_vertices_equal_denoise_of_the_frame(pt, oracle, gpu):
+    """pt_renderer_set_display: Renderer::Render and Denoiser::Denoise (main.cu:148,175; src/denoise.cu:9-29) in ONE kernel.  The
+    vertices every frame then writes must be what the oracle's denoise_kernel makes of the oracle's frame, bit for bit -- for
+    the interactive shape (BASELINE configs[4]: 8 bounces, 4 spp, consecutive frames with the generator state carried over),
+    for every kernel family (one, two and four lanes per pixel, chunked, path regeneration, the pooled grid walk, both
+    generators), for a row tile with ragged waves, and switched off again by NULL; the fast mode's vertices are the display
+    pack of the fast mode's own frame."""
+    def run(w, h, spp, scene, frames=1, tile=None, **kw):
+        basis = pt.camera_basis(width=w, height=h)
+        rb, re_ = tile if tile else (0, h)
+        r = pt.Renderer(w, h, spp, row_begin=rb if tile else 0, row_end=re_ if tile else 0, **kw)
+        d_scene, n = pt.upload_scene(scene)
+        d_out, d_vtx = pt.DeviceBuffer((re_ - rb) * w * 56), pt.DeviceBuffer((re_ - rb) * w * 12)
+        r.set_display(d_vtx.ptr)
+        rng_mode = kw.get("rng_mode", 0)
+        st = oracle.setup_random(w, h) if rng_mode == 0 and not kw.get("fast_math") else None
+        for f in range(frames):
+            d_vtx.upload(np.full(((re_ - rb), w, 3), -3.0, dtype=np.float32))
+            r.render(d_out.ptr, d_scene.ptr, n, basis)
+            got = d_vtx.download(np.float32, (re_ - rb, w, 3))
+            frame = d_out.download(np.float32, (re_ - rb, w, 14))
+            if kw.get("fast_math"):
+                want = pt.display_pack(frame)  # (no tile in this case)
+            else:
+                ref = oracle.render(w, h, spp, spheres=scene, basis=basis, rng_mode=rng_mode, rng_state=st, frame=f,
+                                    max_bounces=kw.get("max_bounces", 5))
+                assert_bit_exact(frame, ref[rb:re_], f"{kw} frame {f}")
+                want = oracle.display_pack(ref)[rb:re_]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{kw} tile {tile} frame {f}"
+        r.set_display(None)
+        d_vtx.upload(np.full(((re_ - rb), w, 3), -3.0, dtype=np.float32))
+        r.render(d_out.ptr, d_scene.ptr, n, basis)
+        assert (d_vtx.download(np.float32, (re_ - rb, w, 3)) == -3.0).all()
+        r.destroy()
+
+    cornell = pt.scene_cornell()
+    run(512, 512, 4, cornell, frames=2, max_bounces=8)                      # the interactive shape, automatic kernel (REF8 build)
+    for rng in (0, 1):
+        for v in (0, 6, 8, 9):
+            run(72, 40, 9, cornell, variant=v, rng_mode=rng)
+        run(72, 40, 601, cornell, variant=6, rng_mode=rng, chunks=4)         # the last chunk writes frame and vertices
+        run(72, 40, 5, pt.scene_random(40, seed=2), variant=10, rng_mode=rng)
+        run(72, 40, 5, pt.scene_random(300, seed=3), variant=13, rng_mode=rng)
+    run(100, 60, 4, cornell, tile=(17, 43), variant=6)                         # a row tile: vertices carry the IMAGE row
+    run(100, 60, 4, cornell, tile=(17, 43), variant=8)
+    run(96, 64, 4, cornell, fast_math=True)
+
+
 def test_cli_preview_is_the_display_packed_frame(pt, oracle, gpu, tmp_path):
     import os
     import subprocess
