@@ -139,6 +139,7 @@ LAB_ABI = {
                                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
                                             ctypes.POINTER(ctypes.c_uint32)]),
     "pt_debug_grid_header": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_debug_policy_ms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }
 
 FN_INV_SQRT_LITERAL, FN_INV_SQRT_FAST, FN_SQRT_LITERAL, FN_SQRT_FAST, FN_SIN, FN_COS, FN_UNIFORM = range(7)
@@ -148,6 +149,8 @@ FN_SIN_LITERAL, FN_COS_LITERAL = 13, 14
 
 lib = ctypes.CDLL(LIB_PATH)
 for _name, (_res, _args) in ABI.items():
+    if os.environ.get("PT_LIB_OVERRIDE") and not hasattr(lib, _name):
+        continue  # A/B tooling only: an alternative build of an older ABI (tools/build_alt.sh from an older tree)
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export the ABI
     _fn.restype = _res
     _fn.argtypes = _args
@@ -160,7 +163,7 @@ if IS_LAB:
 
 
 def variants():
-    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 9, 10, 11, 13; lab: 0..13)."""
+    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 9, 10, 13; lab: 0..13)."""
     out = []
     o = RendererOpts()
     for v in range(14):
@@ -307,6 +310,23 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def policy_ms(rng_mode, variant, waves_per_simd, spp, bounces=5):
+    """Lab library: the automatic policy's predicted kernel ms for variant 6 / 8 / 9 on a tile (pt_debug_policy_ms)."""
+    ms = ctypes.c_double(0)
+    check(lib.pt_debug_policy_ms(rng_mode, variant, waves_per_simd, spp, bounces, ctypes.byref(ms)))
+    return ms.value
+
+
+def policy_choice(rng_mode, waves_per_simd, spp, bounces=5, with9=True):
+    """... and the variant it therefore picks for the reference's scene (variant 6 keeps a tie)."""
+    best, best_ms = 6, None
+    for v in (6, 8, 9) if with9 else (6, 8):
+        ms = policy_ms(rng_mode, v, waves_per_simd, spp, bounces)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = v, ms
+    return best
 
 
 def grid_header(spheres):

@@ -46,8 +46,7 @@ struct pt_renderer {
   bool auto_variant;
   uint64_t resident_pixels; // one-lane-per-pixel lanes the device holds at four waves per SIMD
   double waves_per_simd;    // one-lane-per-pixel waves of the tile per SIMD
-  bool small_tile;         // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD one-lane-per-pixel waves per SIMD
-  bool philox_split;       // fewer than PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX: where the four-lane kernel wins with the counter-based generator
+  bool small_tile;         // fewer than three one-lane-per-pixel waves per SIMD (many-sphere scenes: four lanes per pixel pay there)
   bool spec_ok;            // variant 8's speculation has not been failing on this scene
   uint32_t* d_fail;        // device counter written by variant 8
   uint32_t* h_fail;        // pinned host copy, valid once ev_fail has completed
@@ -88,30 +87,53 @@ static int mark_last(pt_renderer* r, hipStream_t stream) {
   return PT_OK;
 }
 
-// Variant 8 pays when the tile gives fewer one-lane-per-pixel waves than this per SIMD.  Round 3 (tools/tile_policy.py,
-// profiles/r03/tile_policy.json; 1024 spp, xorwow): with five waves resident, progress priorities and sample chunking the
-// one-lane kernel takes about 3.35 ms per started wave-round, the four-lane kernel 3.65 ms per wave's worth of pixels --
-// 2 waves/SIMD (1/8 frame): 8.09 vs 7.48 ms, 2.5: 10.99 vs 9.12, 3: 10.09 vs 10.92, 3.5: 13.29 vs 12.88, 4 (1/4 frame): 13.41 vs
-// 14.53, 5: 16.46 vs 18.36 (rounds 1-2: 6).  philox (no skip-ahead): 4: 14.31 vs 13.45, 5: 16.88 vs 17.14, 8: 26.2 vs 26.9
-// (round 2: 12).
-// In the reference configuration (9 spheres, 5 or 8 bounces) there is a kernel in between: variant 9, TWO lanes per pixel, a
-// third of the skip-ahead, one round of four waves on a tile of two one-lane waves per SIMD (the 1/8 frame: 6.90 ms against
-// 7.55 and 8.14); by one-lane waves per SIMD w, kernel ms of variants 6 / 8 / 9: 1: 6.87 / 3.94 / 4.50, 1.5: 8.18 / 5.76 / 5.57,
-// 2: 8.14 / 7.55 / 6.90, 2.5: 11.08 / 9.14 / 9.53, 3: 10.17 / 10.98 / 10.59, 3.5: 13.33 / 12.91 / 11.99, 4: 13.37 / 14.53 / 14.19,
-// 5: 16.54 / 18.45 / 17.52.  The steps are wave counts: variant 6 takes ceil(w) wave times, variant 9 ceil(2w / 4) rounds.
-#define PT_SPLIT_MAX_WAVES_PER_SIMD 3
-#define PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX 5
+// ---- which kernel for a small scene: a cost model instead of a table of bands (round 4) ---------------------------------
+// Three kernels render the reference's scene bit-identically: variant 6 (one lane per pixel), 9 (two) and 8 (four).  More lanes
+// per pixel = more, shorter waves: they fill a tile that gives each SIMD only a wave or two, and they pay for it with the
+// generator skip-ahead and the record exchange.  Per kernel, three measured constants describe a SIMD that holds k of its
+// waves (ms per 1024 samples of 5 bounces): L, what one wave needs alone (latency-bound), I, what each wave adds once the SIMD
+// is issue-bound -- time(k) = (L^4 + (k I)^4)^(1/4), the smooth maximum of the two regimes -- and the round size, the waves a
+// SIMD works on at a time when the frame is too short for sample chunking (then the tile is whole rounds plus a rest; a
+// chunked frame fills its tail and behaves as one round of any size).  Unchunked waves run `unchunked` times slower (their
+// tail is not filled) and every wave costs `per_wave` of prologue.  The tile has w one-lane waves per SIMD, hence
+// ceil(lanes * w) waves of the kernel in question.  Fitted to profiles/r04/tile_policy_sweep.txt (row tiles of the headline
+// frame, 1024 spp, both generators: the model's choice is within 0.5 % of the measured optimum at every point) and
+// profiles/r04/short_frames_*.txt (256^2 ... 640^2 at 4 ... 256 spp: within 2.3 %); tests/test_policy_model.py keeps it so.
+struct KernelCost {
+  int variant, lanes;
+  double L, I;
+  int round;
+  double unchunked, per_wave;
+};
+static const KernelCost kKernelCost[2][3] = {
+    // cuRAND XORWOW (the split kernels re-generate their partners' draws)
+    {{6, 1, 6.58, 2.97, 5, 1.031, 0.00666}, {8, 4, 1.85, 0.868, 5, 1.076, 0.00248}, {9, 2, 3.40, 1.60, 8, 1.108, 0.00448}},
+    // Philox (counter-based: no skip-ahead)
+    {{6, 1, 6.67, 3.05, 5, 1.031, 0.00666}, {8, 4, 1.75, 0.810, 8, 1.076, 0.00248}, {9, 2, 3.35, 1.60, 8, 1.108, 0.00448}}};
+static const double kLaunchMs = 0.012;
 
-// the split kernel (8, 9) or 6 for a small xorwow tile of the reference configuration, by one-lane waves per SIMD
-// (with sample chunking in the split kernels too -- chunks 1 / 4 / 5, tools/chunk_tile.py: variant 9 w = 2: 6.94 / 6.81 / 6.76 ms,
-// 2.5: 9.67 / 8.43 / 8.47, 3.5: 11.95 / 11.79 / 11.72, 1: 4.68 / 4.39 / 4.40; variant 8 w = 1: 3.84 / 3.68 / 3.74, 2.5: 9.11 / 9.08 / 9.12 --
-// the two-lane kernel also takes the band around 2.5)
-static int small_tile_variant(double w) {
-  if (w <= 1.25) return 8;
-  if (w < 2.75) return 9;
-  if (w <= 3.0) return PT_DEFAULT_VARIANT;
-  if (w <= 3.5) return 9;
-  return PT_DEFAULT_VARIANT;
+static double predicted_ms(const KernelCost& c, double w, int spp, int bounces, bool chunked) {
+  auto simd = [&](double k) { return c.I > 0 ? pow(pow(c.L, 4) + pow(k * c.I, 4), 0.25) : 0.0; };
+  const double k = ceil(c.lanes * w - 1e-9), u = chunked ? 1.0 : c.unchunked;
+  double t = simd(k);
+  if (!chunked && k > c.round) {
+    const double full = floor(k / c.round), rest = k - full * c.round;
+    t = full * simd(c.round) + (rest > 0 ? simd(rest) : 0.0);
+  }
+  return kLaunchMs + k * c.per_wave + u * t * spp / 1024.0 * bounces / 5.0;
+}
+
+// the cheapest of variants 6, 8 (and 9 where it has a build: the reference configuration) for this tile
+static int cheapest_variant(int rng_mode, double w, int spp, int bounces, bool with9) {
+  const bool chunked = spp >= 512;  // (every one of the three chunks its samples from there on, pt_renderer_create)
+  int best = PT_DEFAULT_VARIANT;
+  double best_ms = 1e300;
+  for (const KernelCost& c : kKernelCost[rng_mode == PT_RNG_PHILOX ? 1 : 0]) {
+    if (c.variant == 9 && !with9) continue;
+    const double ms = predicted_ms(c, w, spp, bounces, chunked);
+    if (ms < best_ms) best = c.variant, best_ms = ms;  // (variant 6 comes first: it keeps a tie)
+  }
+  return best;
 }
 
 static int effective_variant(pt_renderer* r, int n_spheres) {
@@ -121,49 +143,16 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
     r->fail_pending = false;
     if (*r->h_fail > r->tile_pixels / 50u) r->spec_ok = false;  // > 2 % of the pixels left speculative mode: an open scene
   }
-  // Many-sphere scenes: a bounce is n sphere tests, so neither the unrolled path of variant 6 nor more
-  // lanes per pixel matter; what does is that lanes whose path left the scene do not idle (open
-  // 1000-sphere scene: 35.5 -> 25.7 ms at 16 spp; closed scenes: equal to variant 6).
-  // A small closed tile still gains from four lanes per pixel (1/8 tile, 1000 spheres + walls: 17.9 vs 23.3 ms);
-  // the speculation feedback above sends an open scene back to variant 10.
-  // fewer tests: the uniform grid, its sphere tests pooled across the lanes of a wave (variant 13; 11 is the same walk with
-  // every lane testing its own spheres: 1000 spheres + walls 132 -> 100 ms, open 47 -> 40 ms, profiles/r03)
+  // Many-sphere scenes: a bounce is n sphere tests; what matters is WHICH spheres are tested (the uniform grid with pooled
+  // tests, variant 13: 160 ... 2048 spheres) and that lanes whose path left the scene do not idle (path regeneration, variant
+  // 10); a small closed tile still gains from four lanes per pixel until the speculation feedback says the scene is open.
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
-  if (n_spheres > PT_SCREEN_MAX_SPHERES)
-    return (r->opts.rng_mode == PT_RNG_XORWOW && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
-  // philox is counter-based: no skip-ahead, no speculation.  Frames whose samples are chunked (spp >= 512): the four-lane kernel
-  // wins below five one-lane waves per SIMD, the one-lane kernel above (numbers at PT_SPLIT_MAX_WAVES_PER_SIMD).  Shorter
-  // frames are whole rounds of waves to the one-lane kernel -- R resident per SIMD: five in the 5-bounce reference build, else
-  // four -- and it wins where its rounds are nearly full (512^2 = 4 waves per SIMD, 64 spp: 0.82 against 0.88 ms; config 5's
-  // shape with philox 0.096 against 0.105), the four-lane kernel where a round would be mostly empty (576^2: 1.14 against 1.32);
-  // from three rounds on the tail no longer matters (profiles/r03/philox_policy.txt, philox_low.txt).
-  if (r->opts.rng_mode == PT_RNG_PHILOX) {
-    if (r->spp < 4) return PT_DEFAULT_VARIANT;
-    if (r->spp >= 512) return r->philox_split ? 8 : PT_DEFAULT_VARIANT;
-    const bool ref5 = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 6, r->opts.layout == PT_LAYOUT_PLANAR) == 5;
-    const double resident = ref5 ? (double)PT_REF_MIN_WAVES_PHILOX : (double)PT_MIN_WAVES;
-    const double rounds = ceil(r->waves_per_simd / resident);
-    if (rounds >= 3.0) return PT_DEFAULT_VARIANT;
-    return r->waves_per_simd < 0.78 * rounds * resident ? 8 : PT_DEFAULT_VARIANT;
-  }
-  // xorwow: splitting must amortise the generator skip-ahead and only pays on small tiles
-  if (!r->spec_ok) return PT_DEFAULT_VARIANT;
+  const bool xorwow = r->opts.rng_mode == PT_RNG_XORWOW;
+  if (n_spheres > PT_SCREEN_MAX_SPHERES) return (xorwow && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
+  // splitting a pixel's samples over lanes needs samples to split, and (xorwow) a speculation that holds
+  if (r->spp < 4 || (xorwow && !r->spec_ok)) return PT_DEFAULT_VARIANT;
   const bool ref = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0;
-  // (four to seven samples per pixel: only where one wave per SIMD would run alone -- 256^2 x 4 spp: 0.042 against 0.056 ms)
-  if (r->spp < 8) return (ref && r->spp >= 4 && r->waves_per_simd <= 1.25) ? 8 : PT_DEFAULT_VARIANT;
-  if (ref) {  // the reference configuration: every kernel has a build for it
-    int v = small_tile_variant(r->waves_per_simd);
-    // Frames too short for sample chunking, from 64 spp up (profiles/r03/short_frames_xorwow.txt): below 2.75 waves per SIMD the
-    // four-lane kernel beats the two-lane one (320^2 x 64 spp: 0.456 against 0.493 ms), and where the one-lane kernel's second
-    // round of five resident waves would be mostly empty the two-lane kernel beats it (576^2: 1.20 against 1.29)
-    if (r->spp < 512 && r->spp >= 64) {
-      const double resident = (double)PT_REF_MIN_WAVES, rounds = ceil(r->waves_per_simd / resident);
-      if (r->waves_per_simd < 2.75) v = 8;
-      else if (rounds == 2.0 && r->waves_per_simd < 0.56 * rounds * resident) v = 9;
-    }
-    return v;
-  }
-  return r->small_tile ? 8 : PT_DEFAULT_VARIANT;
+  return cheapest_variant(r->opts.rng_mode, r->waves_per_simd, r->spp, r->opts.max_bounces > 0 ? r->opts.max_bounces : 1, ref);
 }
 
 // opts.chunks, or env PT_CHUNKS when that is 0: 0 = automatic, 1 = never, 2..PT_CHUNKS_MAX = that many (anything else: automatic)
@@ -291,8 +280,8 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   if (o.chunks < 0 || o.chunks > PT_CHUNKS_MAX || o.reserved != 0)
     return pt_fail(PT_EINVAL, "pt_renderer_create: chunks %d (0 = automatic, 1 = off, 2..%d), reserved %d (must be 0)", o.chunks, PT_CHUNKS_MAX, o.reserved);
   if (o.variant != PT_VARIANT_AUTO && !pt_kernel_has_variant(o.variant))
-    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 9, 10, 11, 13; "
-                              "the experiments 1-5, 7, 12 live in libptcore_lab.so)", o.variant);
+    return pt_fail(PT_EINVAL, "pt_renderer_create: kernel variant %d is not in this build (product variants: 0, 6, 8, 9, 10, 13; "
+                              "the experiments 1-5, 7, 11, 12 live in libptcore_lab.so)", o.variant);
   // 32-bit pixel ids like the reference (pathtrace.cu:206): width*height must fit uint32
   if ((uint64_t)width * (uint64_t)height > 0xFFFFFFFFull) return pt_fail(PT_EINVAL, "pt_renderer_create: image too large");
 
@@ -315,7 +304,6 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
   r->small_tile = false;
   r->resident_pixels = 0;
   r->waves_per_simd = 1e9;
-  r->philox_split = true;
   r->spec_ok = true;
   r->d_fail = nullptr;
   r->h_fail = nullptr;
@@ -346,8 +334,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
       const uint64_t simds = (uint64_t)prop.multiProcessorCount * 4u;
       r->resident_pixels = simds * 4u * 64u;
       r->waves_per_simd = (double)r->tile_pixels / (double)(simds * 64u);
-      r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD;
-      r->philox_split = (uint64_t)r->tile_pixels < simds * 64u * PT_SPLIT_MAX_WAVES_PER_SIMD_PHILOX;
+      r->small_tile = (uint64_t)r->tile_pixels < simds * 64u * 3u;
     }
   }
   if (e == hipSuccess) e = hipMalloc((void**)&r->d_fail, sizeof(uint32_t));
@@ -394,7 +381,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
       r->chunks13 = fit_chunks(want13, r->spp, PT_CHUNK_MAX_SAMPLES_GRID);
     }
     // the split kernels (small tiles of the reference configuration: one or two rounds of waves by construction): four chunks
-    // (numbers at small_tile_variant)
+    // (tools/chunk_tile.py, profiles/r03/tile_policy_bitops.txt)
     r->chunks_split = fit_chunks(asked == 0 && r->spp >= 512 ? PT_CHUNKS_SPLIT : asked, r->spp, PT_CHUNK_MAX_SAMPLES);
     int khz = 0;  // s_memrealtime ticks per millisecond
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
@@ -654,6 +641,19 @@ int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames) {
   if (repaired_frames) *repaired_frames = r->repaired;
   return check_device_error(r, wait != 0);
 }
+
+#if PT_BUILD_EXPERIMENTS
+// lab library: the policy's cost model, for tests/test_policy_model.py (include/ptcore_lab.h)
+int pt_debug_policy_ms(int rng_mode, int variant, double waves_per_simd, int spp, int bounces, double* ms) {
+  if (!ms) return pt_fail(PT_EINVAL, "pt_debug_policy_ms: ms is NULL");
+  for (const KernelCost& c : kKernelCost[rng_mode == PT_RNG_PHILOX ? 1 : 0])
+    if (c.variant == variant) {
+      *ms = predicted_ms(c, waves_per_simd, spp, bounces, spp >= 512);
+      return PT_OK;
+    }
+  return pt_fail(PT_EINVAL, "pt_debug_policy_ms: no cost record for variant %d", variant);
+}
+#endif
 
 int pt_renderer_set_display(pt_renderer* r, float* d_vertices) {
   if (!r) return pt_fail(PT_EINVAL, "pt_renderer_set_display: renderer is NULL");

@@ -52,7 +52,12 @@
 #define PT_REF_MIN_WAVES 5  // ... of the reference-configuration builds of variant 6 (<= 96 VGPRs)
 #endif
 #ifndef PT_REF_MIN_WAVES_PHILOX
-#define PT_REF_MIN_WAVES_PHILOX 5  // ... and of the 5-bounce philox build (the 8-bounce one keeps PT_MIN_WAVES)
+// ... the philox builds keep four.  Round 3 gave the 5-bounce philox build five (one spilled word, whole frame 48.7 -> 48.0 ms);
+// round 4 measured what the scratch memory that build needs does to CHUNKED launches -- every workgroup of a kernel with
+// scratch is slow to start, and a chunked tile is 6-8 times as many workgroups: a quarter frame (8 chunks) 13.8 ms against
+// 12.2 with four waves and no scratch, a 64-row tile 13.6 against 6.6 -- for 0.7 % on the whole frame
+// (profiles/r04/philox_waves.txt).
+#define PT_REF_MIN_WAVES_PHILOX 4
 #endif
 // LDS the scene image may take per workgroup (gfx950 has 160 KiB per CU; one workgroup may
 // use all of it; this budget still lets a full-size scene run with one workgroup per CU and the

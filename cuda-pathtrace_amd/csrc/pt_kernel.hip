@@ -886,9 +886,9 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int r
       case 6: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, true>;
       case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
       case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
-      case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
       case 13: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 13, true> : pt::pixel_kernel<PT_RNG_XORWOW, 13, true>;
-#if PT_BUILD_EXPERIMENTS
+#if PT_BUILD_EXPERIMENTS  // variant 11 (the grid walk with every lane testing its own spheres): superseded by 13, kept for A/B
+      case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
       case 12: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 12, true> : pt::pixel_kernel<PT_RNG_XORWOW, 12, true>;
 #endif
       default: return nullptr;
@@ -945,7 +945,7 @@ bool pt_kernel_has_variant(int variant) {
 #if PT_BUILD_EXPERIMENTS
   return true;
 #else
-  return variant == 0 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 11 || variant == 13;
+  return variant == 0 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 13;
 #endif
 }
 

@@ -1,7 +1,7 @@
 /*
  * ptcore_lab.h -- additional exports of libptcore_lab.so, the LAB build of the same sources
  * (csrc/Makefile, -DPT_BUILD_EXPERIMENTS=1): everything in ptcore.h, plus the experimental kernel
- * variants 1-5, 7 and 12 (stepping stones and measured negative results) and the
+ * variants 1-5, 7, 11 and 12 (stepping stones, superseded kernels and measured negative results) and the
  * diagnostic entry points below.  Loaded by the variant / exhaustive tests and the tools; the
  * product library libptcore.so exports none of this.  No reference counterpart.
  */
@@ -47,6 +47,10 @@ int pt_debug_div_compare(uint32_t n_first, uint32_t n_count, uint32_t first_bits
 /* Diagnostics: builds the uniform grid of kernel variant 11 for a scene and returns its 64-byte header
  * {valid, nx, ny, nz, origin xyz, cell size, 1/cell size, slack, centre xyz, (2E)^2, n_big, n_items}. */
 int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]);
+/* The automatic policy's cost model (csrc/pt_capi.hip, "which kernel for a small scene"): predicted kernel milliseconds of
+ * variant 6, 8 or 9 on a tile of `waves_per_simd` one-lane waves per SIMD at `spp` samples and `bounces` bounces.  Host
+ * arithmetic only (no device needed): tests/test_policy_model.py holds it against the measured sweeps under profiles/. */
+int pt_debug_policy_ms(int rng_mode, int variant, double waves_per_simd, int spp, int bounces, double* ms);
 
 #ifdef __cplusplus
 }

@@ -41,4 +41,4 @@ def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
     uses = [m.start() for m in re.finditer(r"load_oracle\(\)", src)]
     assert len(uses) == 1
     # the single use sits in the cpu_baseline branch, after the timed region has been reported
-    assert src.index('out["cpu_baseline"] = cpu_baseline(') > uses[0] > src.index("renderer, elapsed, kernel_s = measure(rng_mode)")
+    assert src.index('out["cpu_baseline"] = cpu_baseline(') > uses[0] > src.index("renderer, elapsed, kernel_s = measure(rng_mode")

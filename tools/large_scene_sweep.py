@@ -9,7 +9,7 @@ for n in (600, 800, 850, 860, 900, 1000):
     sc = pt.scene_random(n, seed=1, with_walls=True)
     d_scene, ns = pt.upload_scene(sc)
     row = []
-    for v in (6, 8, 10, 11):
+    for v in (6, 8, 10, 13):
         r = pt.Renderer(1024, 1024, 8, variant=v, rng_mode=pt.RNG_PHILOX)
         ms = min(r.render(d_out.ptr, d_scene.ptr, ns, basis) for _ in range(2))
         ki = r.kernel_info(ns)

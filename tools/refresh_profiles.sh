@@ -10,7 +10,6 @@ python3 tools/summarise_profile.py cfg2_philox $R > /dev/null
 python3 tools/summarise_profile.py cfg2_fast $R > /dev/null
 python3 tools/summarise_profile.py cfg4_v13_closed $R > /dev/null
 python3 tools/summarise_profile.py cfg4_v13_open $R > /dev/null
-python3 tools/summarise_profile.py cfg4_v11_closed $R > /dev/null
 python3 tools/summarise_profile.py cfg5_xorwow $R > /dev/null
 python3 tools/summarise_profile.py cfg3_xorwow $R > /dev/null
 rm -f profiles/hbm_traffic.json profiles/valu_roofline.json
