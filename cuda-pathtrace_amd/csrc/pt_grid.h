@@ -617,6 +617,8 @@ struct GridWalk {
   bool have_next;
   bool walking;                    // the DDA can still move on: neither stopped nor out of the box
   uint32_t e0, e1;                 // variant 13: the entry cell's table entry (layout: head of this file), count 0 if the ray misses the box
+  float t_box;                     // variant 13: the ray parameter at which it leaves the grid box (+ 2 slacks)
+  bool forced;                     // variant 13: the walk was cut short by the safety cap on its rounds -- the result is not to be trusted
   __device__ __forceinline__ bool busy() const { return (k0 < k1) | have_next | walking; }
 };
 
@@ -713,6 +715,8 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   w.e0 = 0u;
 #endif
   w.walking = active;
+  w.t_box = t_out + 2.0f * slack_t;
+  w.forced = false;
   PT_STAT(0, 1);
   PT_STAT(5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
 }
@@ -831,7 +835,7 @@ __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, 
   const float Tlim = 1000000.0f * (2.0f * w.a);
   const Near2& s = w.s;
   const bool has = s.T1 < INF;
-  bool ambiguous = has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f));
+  bool ambiguous = (has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f))) | w.forced;  // (forced: variant 13's round cap)
   float t;
   bool bad = false;
   const RayConst rc = make_ray_const(d);
@@ -947,23 +951,29 @@ __device__ __forceinline__ float bperm_f(int byte_addr, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
-// One DDA step (grid_trips: same rule, same arithmetic); returns whether the lane still walks, i.e. stands in a new cell.
+// One DDA step of the pooled walk; returns whether the lane still walks, i.e. stands in a new cell.  Round 4: the whole stop
+// rule is ONE compare of the ray parameter at which the lane leaves its cell against `tstop`, the smallest of
+//   * the parameter beyond which nothing can beat or tie the best estimate: T1 (1 + 2^-17) / 2a + slack_t  (grid_trips' rule
+//     "T1 (1 + 2^-17) < 2a (t_exit - slack_t)" solved for t_exit),
+//   * the 1e6 acceptance limit in the same units,
+//   * the parameter at which the ray leaves the grid box, plus two slacks (instead of per-axis cell counters: the box is the
+//     spheres' bounding box inflated by more than a slack beyond every registration, so nothing is registered out there),
+// all three rounded UP (a later stop visits more cells: more tests, same result).  A lane may thus step one cell past the box
+// before the test fires; the cell index it READS is clamped into the table (any cell's spheres are valid extra tests).
+// Termination: tmax grows by tdel >= cs / |d| per step of its axis, a normal float for every admitted ray (|d| < 1e15), and a
+// NaN fails the compare -- and the caller caps the rounds of a walk regardless (GridWalk::forced).
 // (A free function with the strides BY VALUE: inside a lambda that captures them by reference the select between them becomes a
 // select of addresses and a load from scratch memory, see grid_trips.)
 __device__ __forceinline__ bool dda_step(float& tmax0, float& tmax1, float& tmax2, float tdel0, float tdel1, float tdel2, int& cidx,
-                                         int cs0, int cs1, int cs2, uint32_t& left, float T1, float slack_t, float two_a, float Tcap) {
+                                         int cs0, int cs1, int cs2, float tstop) {
   const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
-  const float reach = (t_exit - slack_t) * two_a;
-  // nothing that could still matter lies beyond the cell being left: stop
-  const bool stop = (T1 * 1.0000077f < reach) | (reach > Tcap);
   const bool a0 = (tmax0 <= tmax1) & (tmax0 <= tmax2);
   const bool a1 = !a0 & (tmax1 <= tmax2);
   tmax0 = a0 ? tmax0 + tdel0 : tmax0;
   tmax1 = a1 ? tmax1 + tdel1 : tmax1;
   tmax2 = (a0 | a1) ? tmax2 : tmax2 + tdel2;
   cidx += a0 ? cs0 : (a1 ? cs1 : cs2);
-  left -= a0 ? 1u : (a1 ? (1u << 10) : (1u << 20));
-  return !stop & ((left & 0x20080200u) == 0x20080200u);
+  return t_exit <= tstop;
 }
 
 // The walk of variant 13 (between grid_begin<true> and grid_end).  Every lane that is in the function helps testing; `walk`
@@ -976,12 +986,20 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   const float two_a = 2.0f * walk.a;
   const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(walk.a);
   const float Tcap = 1000000.0f * two_a * 1.0000153f;  // the walk ends where 2a t passes the 1e6 limit
+  const float inv_two_a = __builtin_amdgcn_rcpf(two_a);
   float tmax0 = walk.tmax0, tmax1 = walk.tmax1, tmax2 = walk.tmax2;
   const float tdel0 = walk.tdel0, tdel1 = walk.tdel1, tdel2 = walk.tdel2;
   int cidx = walk.cidx;
   const int cs0 = walk.cs0, cs1 = walk.cs1, cs2 = walk.cs2;
-  uint32_t left = walk.left;
+  const uint32_t last_cell = G.h.nx * G.h.ny * G.h.nz - 1u;
+  const float t_box = walk.t_box;
+  // where the walk stops (dda_step), from the best estimate as of the last drain; 1 + 2^-19 covers the roundings of this line
+  auto stop_at = [&](float best) { return fminf(fmaf(fminf(best * 1.0000077f, Tcap), inv_two_a, slack_t), t_box) * 1.0000019f; };
   bool walking = walk.walking;
+  // safety net: a monotone walk crosses at most nx + ny + nz cells; a wave that needs more rounds than that holds a lane whose
+  // DDA does not advance (no admitted ray does that) -- such lanes are stopped and their result is left to the literal loop
+  // (plus the chained table entries: a lane that follows a link does not step in that round)
+  int rounds_left = (int)(G.h.nx + G.h.ny + G.h.nz) / K + 8 + (int)((G.h.n_big >> 16) - (last_cell + 1u));
   // lanes of this wave that are here (the others are on the brute-force path, or their pixel is finished): ranks, not lane
   // numbers, index the ring
   const uint64_t here = __builtin_amdgcn_ballot_w64(true);
@@ -994,7 +1012,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   __hip_atomic_store(P.t2 + lane, __float_as_uint(walk.s.T2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t links = 0u;   // chained table entries this lane still has to follow: a queue of two 16-bit slots (see (3))
   uint32_t tail = 0u;    // wave-uniform: entries in the ring, which always starts at slot 0 when a push begins
-  float T1 = walk.s.T1;  // the owner's best estimate as of the last drain
+  float tstop = stop_at(walk.s.T1);  // (the owner's best estimate as of the last drain: nothing but a drain changes it)
   const uint32_t tag = (uint32_t)lane << 16;
   PT_HIST_DECL;
 
@@ -1092,10 +1110,14 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
         if (rank < rest) P.ring[rank] = v;
       }
       tail = rest;
-      // (nothing but a drain changes a best estimate)
-      T1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(P.key1 + lane) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      tstop = stop_at(__uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(P.key1 + lane) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
     }
     if (fin) break;
+    if (__builtin_expect(--rounds_left < 0, 0)) {  // (wave-uniform)
+      walk.forced = walk.forced | walking | (links != 0u);
+      walking = false;
+      links = 0u;
+    }
     // (3) the next entries.  A lane that holds links follows ONE of them (the entry it reads may add another: its round ends
     // there) -- the high slot's if there is one, so that the slot its new entry 0 may write a link to is free; a lane without
     // links takes K DDA steps.  At most two links are ever pending: two from the K cells of a stepping round, or the one left
@@ -1115,20 +1137,22 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
     bool go = chain;
     if (!chain & walking) {
       PT_HIST_LANE(hist_steps, 1);
-      walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, left, T1, slack_t, two_a, Tcap);
+      walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, tstop);
       go = walking;
     }
     if (go) {
-      const uint2 e = G.cells[chain ? (int)cur : cidx];
+      const uint32_t at = (uint32_t)cidx < last_cell ? (uint32_t)cidx : last_cell;  // (a step past the box: any cell will do)
+      const uint2 e = G.cells[chain ? cur : at];
       e0[0] = e.x, e1[0] = e.y;
     }
 #pragma unroll
     for (int k = 1; k < K; k++) {
       if (!chain & walking) {
         PT_HIST_LANE(hist_steps, 1);
-        walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, left, T1, slack_t, two_a, Tcap);
+        walking = dda_step(tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, tstop);
         if (walking) {
-          const uint2 e = G.cells[cidx];
+          const uint32_t at = (uint32_t)cidx < last_cell ? (uint32_t)cidx : last_cell;
+          const uint2 e = G.cells[at];
           e0[k] = e.x, e1[k] = e.y;
         }
       }

@@ -288,7 +288,9 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     w.tmax0 = w.tmax1 = w.tmax2 = w.tdel0 = w.tdel1 = w.tdel2 = 0.0f;
     w.cidx = w.cs0 = w.cs1 = w.cs2 = 0;
     w.left = w.k0 = w.k1 = w.n0 = w.n1 = 0u;
-    w.have_next = w.walking = false;
+    w.have_next = w.walking = w.forced = false;
+    w.e0 = w.e1 = 0u;
+    w.t_box = 0.0f;
     bool in_walk = false;  // a ray's search is under way
     bool brute = false;    // ... on the brute-force path (the grid is absent or does not admit the ray)
     for (;;) {
