@@ -63,6 +63,14 @@ class Camera {
     updateCameraVectors();
   }
 
+  // Camera.h:115-123.  (The field of view the rays are built with does not follow Zoom: getEyeRayBasis hard-codes 45 degrees,
+  // Camera.h:130 -- scrolling changes the member and nothing else, here as there.)
+  void ProcessMouseScroll(float yoffset) {
+    if (Zoom >= 1.0f && Zoom <= 45.0f) Zoom -= yoffset;
+    if (Zoom <= 1.0f) Zoom = 1.0f;
+    if (Zoom >= 45.0f) Zoom = 45.0f;
+  }
+
   // Camera.h:125-149: four un-normalised corner directions, order (-1,-1) (+1,-1) (-1,+1) (+1,+1).
   void getEyeRayBasis(float3* output, int w, int h) const {
     float pos[3] = {Position.x, Position.y, Position.z}, up[3] = {WorldUp.x, WorldUp.y, WorldUp.z};

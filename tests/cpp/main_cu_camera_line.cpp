@@ -19,5 +19,7 @@ int main() {
   std::cout << "Render completed in " << renderTime << "ms (" << 1000.0f / renderTime << " fps)" << std::endl;  // :183
   Camera scalar(50.0f, 52.0f, 295.6f, 0.0f, 1.0f, 0.0f, -90.0f, 0.0f);  // Camera.h:63-70
   camera.ProcessKeyboard(FORWARD, 0.1f);
-  return (camera.Position.z < scalar.Position.z) ? 0 : 1;
+  camera.ProcessMouseScroll(50.0f);   // Camera.h:115-123: Zoom 45 -> clamped at 1
+  scalar.ProcessMouseScroll(-3.0f);   // 45 -> 48 -> clamped at 45
+  return (camera.Position.z < scalar.Position.z && camera.Zoom == 1.0f && scalar.Zoom == 45.0f) ? 0 : 1;
 }
