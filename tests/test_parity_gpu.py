@@ -141,6 +141,21 @@ def test_thousand_sphere_scene(pt, lab, oracle, gpu, with_walls):
         assert_bit_exact(img, ref, f"1000 spheres walls={with_walls} variant {v}")
 
 
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_sweep_of_the_pooled_walk(pt, lab, oracle, gpu, rng):
+    """Variant 13 leaves its lock-step DDA rounds for the sweep (pt_grid.h, grid_trips_pooled (2b)) once few lanes of a wave
+    still walk: a full frame of complete waves over a 600-sphere scene (rays that stop in every cell of their way), closed and
+    open, both generators, product and lab builds (two register allocations of the same source: DESIGN.md A.12)."""
+    size = 64  # 4096 pixels: complete waves only, the sweep's precondition
+    basis = pt.camera_basis(width=size, height=size)
+    for walls in (True, False):
+        sph = pt.scene_random(600, seed=11, with_walls=walls)
+        ref = oracle.render(size, size, 2, spheres=sph, basis=basis, rng_mode=rng)
+        for mod in (pt, lab):
+            img, _ = mod.render_frame(size, size, 2, spheres=sph, basis=basis, rng_mode=rng, variant=13)
+            assert_bit_exact(img, ref, f"sweep, 600 spheres walls={walls} {'lab' if mod is lab else 'product'}")
+
+
 def test_interactive_shape_eight_bounces(pt, oracle, gpu):
     """config 5 shape: 4 spp per frame, 8-bounce cap, several frames into one device buffer."""
     size = 64
