@@ -1270,6 +1270,8 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
         // rays are packed in lane order and the first starts at slot 0: the ray of slot j is the (number of starts in 1..j)-th
         const uint32_t ray = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
         const bool serving = (uint32_t)lane < (served < 64u ? served : 64u);
+        PT_STATW(3, 1);  // (instrumented builds count a pass as a round, its crossings as the lanes stepping)
+        PT_STATW(4, served < 64u ? served : 64u);
         sw_done += take;
         // (the fetches by EVERY lane, serving or not: ds_bpermute reads nothing from a lane that is masked off, and a ray's owner
         // need not be among the serving lanes)
