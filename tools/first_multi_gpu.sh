@@ -51,4 +51,5 @@ for cfg in ("cfg2", "cfg3"):
         print(f"| {cfg} | {n} | {eng} | {same} | {j['roofline']['kernel_ms']} | {j['ms_per_step']} | {j.get('frame_latency_ms', '-')} | "
               f"{j.get('exchange_exposed_ms', '-')} | {j['value']} | {eff} |")
 PY
+rm -f "$OUT"/*.npy  # (the frames: 59 MB for cfg2, 940 MB for cfg3 each)
 echo "table: $OUT/summary.txt (paste into BASELINE.md section 4 and DESIGN.md section 5)"
