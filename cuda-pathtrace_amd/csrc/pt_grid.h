@@ -934,6 +934,17 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 #ifndef PT_POOL_STEPS
 #define PT_POOL_STEPS 2
 #endif
+#ifdef PT_DEBUG_PIXEL  // never defined in a shipped build: device printf for one pixel's walks (block, thread given on the command line)
+#define PT_DBG_ME() (blockIdx.x == PT_DEBUG_BLOCK && threadIdx.x == PT_DEBUG_THREAD)
+#define PT_DBG_MY_WAVE() (blockIdx.x == PT_DEBUG_BLOCK && (threadIdx.x >> 6) == (PT_DEBUG_THREAD >> 6))
+#define PT_DBG_OWNED(owner) (PT_DBG_MY_WAVE() && (owner) == (PT_DEBUG_THREAD & 63))
+#define PT_DBG(...) do { printf(__VA_ARGS__); } while (0)
+#else
+#define PT_DBG_ME() false
+#define PT_DBG_MY_WAVE() false
+#define PT_DBG_OWNED(owner) false
+#define PT_DBG(...) do { } while (0)
+#endif
 #ifndef PT_POOL_SCAN_DPP
 #define PT_POOL_SCAN_DPP 1  // the sweep's prefix sum: 1 = DPP row shifts and broadcasts, 0 = six ds_bpermute steps
 #endif
@@ -1030,6 +1041,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   uint32_t tail = 0u;    // wave-uniform: entries in the ring, which always starts at slot 0 when a push begins
   float tstop = stop_at(walk.s.T1);  // (the owner's best estimate as of the last drain: nothing but a drain changes it)
   PT_HIST_DECL;
+  if (PT_DBG_ME()) PT_DBG("ENTRY walking %d tmax %g %g %g tdel %g %g %g cidx %d cs %d %d %d tstop %g t_box %g e0 %08x e1 %08x n_here %u T1 %g o %g %g %g d %g %g %g\n", (int)walking, tmax0, tmax1, tmax2, tdel0, tdel1, tdel2, cidx, cs0, cs1, cs2, tstop, t_box, walk.e0, walk.e1, n_here, walk.s.T1, o.x, o.y, o.z, d.x, d.y, d.z);
   // (1) append an entry's spheres to the ring.  Slots: a lane's are consecutive and start at the exclusive prefix sum of the
   // counts, which three compares and six chained v_mbcnt give (count >= 1, >= 2, >= 3: the count sits in the top two bits).
   // `tag`: the owner of the ray the entry was read for, << 16.  `first`: which of the two link slots a link goes to.
@@ -1143,6 +1155,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
     // few lanes still walk (none holds a link, the wave is complete): the sweep takes over
     if (n_here == 64u && __builtin_amdgcn_ballot_w64(links != 0u) == 0 &&
         __builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) <= PT_POOL_SWEEP_BELOW) {
+      if (PT_DBG_ME()) PT_DBG("SWITCH walking %d walkers %d tmax %g %g %g cidx %d tstop %g rounds_left %d\n", (int)walking, (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)), tmax0, tmax1, tmax2, cidx, tstop, rounds_left);
       sweep = true;
       break;
     }
@@ -1173,6 +1186,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
       const uint2 e = G.cells[chain ? cur : at];
       e0[0] = e.x, e1[0] = e.y;
     }
+    if (PT_DBG_ME()) PT_DBG("STEP0 walking %d chain %d cidx %d entry %08x %08x tmax %g %g %g\n", (int)walking, (int)chain, cidx, e0[0], e1[0], tmax0, tmax1, tmax2);
 #pragma unroll
     for (int k = 1; k < K; k++) {
       if (!chain & walking) {
@@ -1185,6 +1199,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
         }
       }
     }
+    if (PT_DBG_ME()) PT_DBG("STEP1 walking %d cidx %d entry %08x %08x tmax %g %g %g\n", (int)walking, cidx, e0[K - 1], e1[K - 1], tmax0, tmax1, tmax2);
   }
   // (2b) THE SWEEP.  Lock-step DDA rounds are cheap per cell while most lanes walk, and hopeless once few do: a round costs the
   // same 91 vector instructions with 49 lanes stepping or with 5, and a wave-walk of 13.7 rounds averages 18.  Once at most
@@ -1212,6 +1227,7 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
       wide = (n0 | n1 | n2) > 255u;
       sw_n = n0 | (n1 << 8) | (n2 << 16) | (cs0 < 0 ? 1u << 24 : 0u) | (cs1 < 0 ? 1u << 25 : 0u) | (cs2 < 0 ? 1u << 26 : 0u);
       sw_total = n0 + n1 + n2;
+      if (PT_DBG_ME()) PT_DBG("COUNTS n %u %u %u\n", n0, n1, n2);
     }
     // (a count that does not fit its byte -- a grid of more than 255 cells along an axis, crossed end to end: the result is left
     // to the literal loop, like a walk the safety net has cut short)
@@ -1287,15 +1303,28 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
           const bool k0 = li < n0, k1 = !k0 & (li < n0 + n1);
           const uint32_t i = li - (k0 ? 0u : (k1 ? n0 : n0 + n1));
           const float tc = (k0 ? m0 : (k1 ? m1 : m2)) + (float)i * (k0 ? d0 : (k1 ? d1 : d2));
-          auto taken = [&](float tmx, float td) { return tc >= tmx ? (int)((tc - tmx) * __builtin_amdgcn_rcpf(td)) + 1 : 0; };
-          const int c0 = k0 ? (int)i + 1 : taken(m0, d0), c1 = k1 ? (int)i + 1 : taken(m1, d1),
-                    c2 = (k0 | k1) ? taken(m2, d2) : (int)i + 1;
+          // How many crossings of another axis m come BEFORE this one: the quotient, biased DOWN by a quarter, is the count or
+          // one short of it (its error is far below that: 255 crossings at most, and a boundary parameter within ulp(t) / tdel of
+          // the real one); the crossing in question then settles it, its parameter formed exactly as that crossing forms its own
+          // tc -- so that every pair of crossings agrees on which of the two comes first (equal parameters: the lower axis).
+          // Without that, two crossings with (nearly) equal parameters can each put itself first, and the cell behind BOTH of
+          // them -- where the ray goes on, for a whole cell's length -- is never visited (seen: tools/grid_check.py
+          // random150_open, one pixel; tests/test_parity_gpu.py::test_sweep_crossings_with_equal_parameters).
+          const int ax = k0 ? 0 : (k1 ? 1 : 2);
+          auto taken = [&](float tmx, float td, int m) {
+            const int j = tc >= tmx ? (int)((tc - tmx) * __builtin_amdgcn_rcpf(td) + 0.75f) : 0;
+            const float tj = tmx + (float)j * td;  // crossing j of axis m (NaN on an axis the ray is parallel to: no change)
+            return ((tj < tc) | ((tj == tc) & (m < ax))) ? j + 1 : j;
+          };
+          const int c0 = k0 ? (int)i + 1 : taken(m0, d0, 0), c1 = k1 ? (int)i + 1 : taken(m1, d1, 1),
+                    c2 = (k0 | k1) ? taken(m2, d2, 2) : (int)i + 1;
           const int sx = (int)G.h.nx, sxy = (int)(G.h.nx * G.h.ny);
           const int idx = base + ((nn >> 24) & 1u ? -c0 : c0) + ((nn >> 25) & 1u ? -c1 : c1) * sx + ((nn >> 26) & 1u ? -c2 : c2) * sxy;
           const uint32_t at = (uint32_t)idx < last_cell ? (uint32_t)idx : last_cell;
           const uint2 e = G.cells[at];
           se0 = e.x, se1 = e.y;
           tag = (info & 0xFFu) << 16;
+          if (PT_DBG_OWNED(info & 0xFFu)) PT_DBG("SERVE helper %d li %u axis %d i %u tc %g c %d %d %d base %d idx %d entry %08x %08x nn %08x\n", lane, li, k0 ? 0 : (k1 ? 1 : 2), i, tc, c0, c1, c2, base, idx, e.x, e.y, nn);
         }
       }
       push(se0, se1, tag, true);
@@ -1309,26 +1338,47 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
   walk.s.T1 = __uint_as_float((uint32_t)(k >> 32));
   walk.s.i1 = walk.s.T1 < INF ? (int)(uint32_t)k : 0;
   walk.s.T2 = __uint_as_float(__hip_atomic_load(P.t2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  if (PT_DBG_ME()) PT_DBG("FINAL T1 %g i1 %d T2 %g forced %d swept %d\n", walk.s.T1, walk.s.i1, walk.s.T2, (int)walk.forced, (int)sweep);
 }
 
+// `walker`: the lane has a ray of its own.  A lane without one (its pixel's samples are done: the tail of every workgroup of a
+// regeneration kernel, where lanes finish at different times) is here to HELP: it draws sphere tests and sweep crossings like
+// everybody else, owns nothing and gets nothing back.
 __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
-                                                            float& t_hit, int& idx) {
+                                                            float& t_hit, int& idx, bool walker = true) {
   GridWalk w;
+  // (no branch around grid_begin for the helpers: they run it on whatever ray they last had -- the wave executes it anyway -- and
+  // their walk is then emptied with selects.  A divergent region that ends here, in front of the register-hungry walk, is where
+  // the allocator's split copies landed in front of the exec restore: DESIGN.md A.12.)
   grid_begin<true>(w, G, o, d, a);
+  const float INF = __builtin_inff();
+  w.s.T1 = walker ? w.s.T1 : INF;
+  w.s.T2 = walker ? w.s.T2 : INF;
+  w.walking = w.walking & walker;
+  w.e0 = walker ? w.e0 : 0u;
+  w.e1 = walker ? w.e1 : 0u;
   grid_trips_pooled(w, G, pool_of_wave(sc.pool), o, d);
+  if (!walker) return false;
   return grid_end(w, sc, G, n, o, d, t_hit, idx);
 }
 
 // variant 13's nearest-hit search
-__device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx) {
+// `live` false: a lane without a ray (see intersect_scene_grid_pooled); it returns false and its outputs are not written
+__device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, bool live = true) {
   if (n <= 0) return false;
   const float a = dot(d, d);
   const GridLds& G = *sc.grid;
   if (G.valid) {
-    const bool admitted = grid_admits(G, o, d, a);
-    PT_STATW(7, __builtin_amdgcn_ballot_w64(!admitted) != 0 ? 1 : 0);
-    if (admitted) return intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx);
+    const bool admitted = live && grid_admits(G, o, d, a);
+    PT_STATW(7, __builtin_amdgcn_ballot_w64(live & !admitted) != 0 ? 1 : 0);
+    // (helpers go in only where somebody walks: wave-uniform)
+    const bool walk_here = __builtin_amdgcn_ballot_w64(admitted) != 0;
+    if (admitted | (walk_here & !live)) {
+      const bool hit = intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx, admitted);
+      if (admitted) return hit;
+    }
   }
+  if (!live) return false;
   return intersect_scene_screened_large(sc, n, o, d, make_ray_const(d), t_hit, idx);
 }
 

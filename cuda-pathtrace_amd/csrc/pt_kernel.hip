@@ -236,9 +236,19 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     const bool by_progress = span >= PT_PRIO_MIN_SPP_REGEN;
     const int q1 = i_begin + span / 4, q2 = i_begin + span / 2, q3 = i_end - span / 4;
     int last_band = -1;
-    while (i < i_end) {
+    // (variant 13: the wave stays together until its LAST lane is done -- lanes that have finished their samples keep going through
+    // the nearest-hit search as helpers of the pooled sphere tests, which otherwise run ever emptier towards the end of every workgroup)
+    for (;;) {
+      const bool live = i < i_end;
+      if constexpr (VAR == 13 && PT_POOL_HELPERS) {
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+      } else {
+        if (!live) break;
+      }
       if (by_progress) {
-        const int iu = __builtin_amdgcn_readfirstlane(i);
+        int iu;  // the first lane that still works
+        if constexpr (VAR == 13 && PT_POOL_HELPERS) iu = __builtin_amdgcn_readlane(i, __builtin_ctzll(__builtin_amdgcn_ballot_w64(live)));
+        else iu = __builtin_amdgcn_readfirstlane(i);
         const int band = (iu >= q1 ? 1 : 0) + (iu >= q2 ? 1 : 0) + (iu >= q3 ? 1 : 0);
         if (band != last_band) {  // wave-uniform
           last_band = band;
@@ -248,7 +258,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
           else __builtin_amdgcn_s_setprio(0);
         }
       }
-      if (n == 0) {  // :219-229
+      if (live & (n == 0)) {  // :219-229
         rng.begin_sample((uint32_t)i);
         primary_ray(rng, d);
         o = eye;
@@ -257,10 +267,10 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       }
       bool escaped = false;
       if (n < a.max_bounces) {
-        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n);
-        n++;
+        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n, live);
+        if (live) n++;
       }
-      if (escaped | (n >= a.max_bounces)) {
+      if (live & (escaped | (n >= a.max_bounces))) {
         if (!escaped) {
           L.color = L.color + color;                 // :198
           if (sc.lean) welford_update(var[0], luminance(color)); else welford_update(var[0], luminance(color), sc.rcpn);  // :200

@@ -73,18 +73,21 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
 
 // LAST (never with n == 0): the path ends after this iteration whatever happens, so nothing but colour is produced -- o, d and
 // the t handed to bounce_shade are dead, and the nearest-hit search may return any t (intersect_scene_screened_keys)
+// `live` (variant 13's regeneration loop only): false for a lane whose pixel is finished -- it goes through the nearest-hit search
+// as a helper of the wave's pooled tests and changes nothing of its own
 template <int RNG, int VAR, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
-                                            Rng<RNG>& rng, Welford (&var)[4], int n) {
+                                            Rng<RNG>& rng, Welford (&var)[4], int n, bool live = true) {
   float t = 0.0f;
   int idx = 0;
   bool hit;
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
   else if constexpr (VAR == 13)
-    hit = intersect_scene_v13(sc, nsph, o, d, t, idx);
+    hit = intersect_scene_v13(sc, nsph, o, d, t, idx, live);
   else
     hit = intersect_scene<VAR, PRIMARY, LAST>(sc, nsph, o, d, t, idx);
+  if (VAR == 13 && !live) return true;
   return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
 }
 

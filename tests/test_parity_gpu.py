@@ -156,6 +156,22 @@ def test_sweep_of_the_pooled_walk(pt, lab, oracle, gpu, rng):
             assert_bit_exact(img, ref, f"sweep, 600 spheres walls={walls} {'lab' if mod is lab else 'product'}")
 
 
+def test_sweep_crossings_with_equal_parameters(pt, lab, gpu):
+    """The frame on which the sweep's first version lost a sphere (tools/grid_check.py, random150_open, third camera): a primary
+    ray whose fourth x-crossing and ninth z-crossing of the grid have the same parameter to the last bit.  Each of the two
+    crossings put itself first, and the cell behind both was never read.  Variant 13 against variant 10 (brute force; bit-exact
+    against the oracle elsewhere) on the whole 1024 x 1024 x 8 spp frame, product and lab builds."""
+    size, spp = 1024, 8
+    scene = pt.scene_random(150, seed=150, with_walls=False)
+    eye = (-150.0, 200.0, 500.0)
+    basis = pt.camera_basis(eye, -55.0, -20.0, size, size)
+    ref, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, variant=10)
+    assert np.count_nonzero(ref[..., 9]) > 5000, "the spheres are not in view"
+    for mod in (pt, lab):
+        img, _ = mod.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, variant=13)
+        assert_bit_exact(img, ref, f"variant 13 vs 10, random150_open camera 2 ({'lab' if mod is lab else 'product'})")
+
+
 def test_interactive_shape_eight_bounces(pt, oracle, gpu):
     """config 5 shape: 4 spp per frame, 8-bounce cap, several frames into one device buffer."""
     size = 64
