@@ -172,6 +172,50 @@ def test_sweep_crossings_with_equal_parameters(pt, lab, gpu):
         assert_bit_exact(img, ref, f"variant 13 vs 10, random150_open camera 2 ({'lab' if mod is lab else 'product'})")
 
 
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_grid_walk_on_rays_whose_crossings_tie(pt, lab, oracle, gpu, rng):
+    """Boundary crossings with EQUAL parameters, by construction: a scene that is symmetric under x <-> y and under the
+    reflections about the eye's x and y (so is its grid: same origin, cell size and cell counts on both axes), a hand-made
+    eye-ray basis with corners (+-0.3125, +-0.3125, -2) and a power-of-two image, 1 sample per pixel (no jitter): every operation that
+    forms a primary ray's direction is exact, |d.x| = |d.y| to the last bit on both image diagonals, and on the main diagonal the
+    x- and y-crossings of the grid tie at EVERY step (on the other one within roundings of the cell boundaries).  The lock-step
+    DDA and the sweep must both walk a lattice path through such rays (the first sweep lost the cell
+    behind two tied crossings).  Then the same scene with jitter (2 spp): near-diagonal rays, near-ties."""
+    g = np.random.default_rng(77)
+    e = 50.0
+    base = pt.scene_random(80, seed=31, with_walls=False)
+    base["pos"][:, 0] = g.uniform(e + 1.0, e + 38.0, len(base)).astype(np.float32)
+    base["pos"][:, 1] = g.uniform(e + 1.0, e + 38.0, len(base)).astype(np.float32)
+    base["pos"][:, 2] = g.uniform(5.0, 95.0, len(base)).astype(np.float32)
+    base["radius"][:] = g.uniform(1.5, 4.0, len(base)).astype(np.float32)
+    parts = []
+    for swap in (False, True):
+        for fx in (False, True):
+            for fy in (False, True):
+                c = base.copy()
+                x, y = (c["pos"][:, 1].copy(), c["pos"][:, 0].copy()) if swap else (c["pos"][:, 0].copy(), c["pos"][:, 1].copy())
+                c["pos"][:, 0] = np.float32(2 * e) - x if fx else x
+                c["pos"][:, 1] = np.float32(2 * e) - y if fy else y
+                parts.append(c)
+    scene = np.concatenate(parts)
+    assert len(scene) == 640
+    hdr = lab.grid_header(scene)
+    assert hdr["valid"] == 1 and hdr["dims"][0] == hdr["dims"][1] and hdr["origin"][0] == hdr["origin"][1], hdr
+    size = 128
+    eye = (e, e, 300.0)
+    k = 0.3125  # (dyadic: the corners, the pixel fractions and their products are exact)
+    basis = np.array([-k, k, -2, k, k, -2, -k, -k, -2, k, -k, -2], dtype=np.float32)
+    for spp in (1, 2):
+        ref = oracle.render(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=rng)
+        assert np.count_nonzero(ref[..., 9]) > size * size // 4, "the spheres are not in view"
+        if spp == 1:  # the picture has the scene's symmetry on the main diagonal only if the rays there are exactly symmetric
+            d = ref[..., 9]
+            assert np.array_equal(d, d.T) or np.array_equal(d, d[::-1, ::-1].T), "the construction does not give symmetric rays"
+        for mod in (pt, lab):
+            img, _ = mod.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=rng, variant=13)
+            assert_bit_exact(img, ref, f"tied crossings, {spp} spp, {'lab' if mod is lab else 'product'}")
+
+
 def test_interactive_shape_eight_bounces(pt, oracle, gpu):
     """config 5 shape: 4 spp per frame, 8-bounce cap, several frames into one device buffer."""
     size = 64
