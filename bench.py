@@ -165,7 +165,8 @@ def profile_records(pt, cfg_key, rng, ki):
             except Exception:
                 rec = None
         if rec is None:
-            why = why or f"no profile for {key}"
+            missing = f"no profile for {key}"
+            why = why or (missing if name == "valu_roofline.json" or not os.path.exists(path) else None)  # (a profile may hold the VALU counters only)
         elif rec.get("fingerprint") != pt.build_fingerprint() or rec.get("num_vgprs") != ki["num_vgprs"]:
             why = f"profile {key} was measured on build {rec.get('fingerprint')} ({rec.get('num_vgprs')} VGPRs), this is {pt.build_fingerprint()} ({ki['num_vgprs']} VGPRs)"
             rec = None
@@ -490,12 +491,18 @@ def main():
             if hrec:
                 traffic = hrec.get("hbm_bytes_per_launch")
             if vrec:  # instruction count per launch is a property of the code; the rate uses THIS run's kernel time
+                # (a profile taken on a shorter launch of the same frame -- config 4: 16 of the 256 spp -- counts per sample)
+                scale = float(WIDTH * HEIGHT * spp) / float(vrec.get("samples_per_launch") or WIDTH * HEIGHT * spp)
+                if scale != 1.0:
+                    vrec = dict(vrec, valu_insts_per_launch=vrec["valu_insts_per_launch"] * scale,
+                                flops_fp32_per_launch=vrec["flops_fp32_per_launch"] * scale, flops_fp64_per_launch=vrec["flops_fp64_per_launch"] * scale,
+                                source=f"{vrec.get('source')}, a {vrec.get('samples_per_launch') // (WIDTH * HEIGHT)}-spp launch scaled by samples")
                 ach = vrec["valu_insts_per_launch"] / kernel_s / 1e9
                 valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
                         "frac": round(ach / VALU_PEAK_GINST, 4),
                         "valu_insts_per_launch": vrec["valu_insts_per_launch"],
-                        "fp32_tflops": round(vrec["flops_fp32_per_launch"] / kernel_s / 1e12, 2),
-                        "fp64_tflops": round(vrec["flops_fp64_per_launch"] / kernel_s / 1e12, 2),
+                        "fp32_tflops": round(vrec["flops_fp32_per_launch"] / kernel_s / 1e12, 2) if vrec["flops_fp32_per_launch"] else None,
+                        "fp64_tflops": round(vrec["flops_fp64_per_launch"] / kernel_s / 1e12, 2) if vrec["flops_fp64_per_launch"] else None,
                         "source": f"{vrec.get('source')} (rocprofv3 SQ_INSTS_VALU per launch / this run's kernel time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles "
                                   "per wave64 instruction, MI355X_MICROARCH.md)"}
                 cw = vrec.get("class_weighted")

@@ -21,5 +21,7 @@ r = pt.Renderer(1024, 1024, spp, variant=variant)
 d_scene, n = pt.upload_scene(scene)
 d_out = pt.DeviceBuffer(1024 * 1024 * 14 * 4)
 ms = [r.render(d_out.ptr, d_scene.ptr, n, basis) for _ in range(reps)]
-print({"spp": spp, "walls": walls, "variant": r.kernel_info(n)["variant"], "ms": [round(m, 3) for m in ms],
-       "Msamples_per_s": round(1024 * 1024 * spp / min(ms) / 1e3, 1)})
+ki = r.kernel_info(n)
+print({"spp": spp, "walls": walls, "variant": ki["variant"], "ms": [round(m, 3) for m in ms],
+       "Msamples_per_s": round(1024 * 1024 * spp / min(ms) / 1e3, 1), "fingerprint": pt.build_fingerprint(), "num_vgprs": ki.get("num_vgprs"),
+       "samples_per_launch": 1024 * 1024 * spp})

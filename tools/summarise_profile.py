@@ -81,5 +81,9 @@ for log in ("stats.log",):
                 ki = out["bench_line_under_profiler"].get("kernel_info", {})
                 out["fingerprint"] = ki.get("fingerprint")  # the build these counters belong to
                 out["num_vgprs"] = ki.get("num_vgprs")
+            elif line.startswith("{'spp'"):  # tools/cfg4_run.py's record
+                import ast
+                rec = ast.literal_eval(line.strip())
+                out["fingerprint"], out["num_vgprs"], out["samples_per_launch"] = rec.get("fingerprint"), rec.get("num_vgprs"), rec.get("samples_per_launch")
 json.dump(out, open(os.path.join(dst, f"{tag}.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in out if k != "bench_line_under_profiler"}, indent=1))
