@@ -144,9 +144,10 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
     if (*r->h_fail > r->tile_pixels / 50u) r->spec_ok = false;  // > 2 % of the pixels left speculative mode: an open scene
   }
   // Many-sphere scenes: a bounce is n sphere tests; what matters is WHICH spheres are tested (the uniform grid with pooled
-  // tests, variant 13: 160 ... 2048 spheres) and that lanes whose path left the scene do not idle (path regeneration, variant
+  // tests, variant 13: 160 ... 2048 spheres, from 72 on tiles that fill the chip) and that lanes whose path left the scene do not idle (path regeneration, variant
   // 10); a small closed tile still gains from four lanes per pixel until the speculation feedback says the scene is open.
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
+  if (n_spheres >= PT_GRID_MIN_SPHERES_LARGE_TILE && n_spheres < PT_GRID_MIN_SPHERES && !r->small_tile) return 13;
   const bool xorwow = r->opts.rng_mode == PT_RNG_XORWOW;
   if (n_spheres > PT_SCREEN_MAX_SPHERES) return (xorwow && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
   // splitting a pixel's samples over lanes needs samples to split, and (xorwow) a speculation that holds

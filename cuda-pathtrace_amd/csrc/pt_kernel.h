@@ -94,6 +94,13 @@
 #endif
 #define PT_GRID_MAX_SPHERES 2048
 #define PT_GRID_MIN_SPHERES 160
+// ... and on tiles that fill the chip (three waves per SIMD and more) already from 72 spheres: with the pooled tests, the sweep and
+// the helpers the grid kernel passes the brute-force one between 60 and 80 spheres (1024^2 x 32 spp, closed / open, variant 10
+// against 13: 60 spheres 5.01 / 1.08 against 5.16 / 1.17 ms, 80: 6.09 / 1.57 against 5.46 / 1.40, 140: 9.43 / 2.81 against
+// 6.18 / 1.79; tools/grid_threshold.py).  Small tiles keep the four-lane / regeneration kernels up to 159.
+#ifndef PT_GRID_MIN_SPHERES_LARGE_TILE
+#define PT_GRID_MIN_SPHERES_LARGE_TILE 72
+#endif
 
 // Everything pixel_kernel needs travels as kernel arguments (SGPRs): the camera is 60 B, so
 // the reference's two per-frame cudaMemcpy H2D (Renderer.h:59-60) disappear.

@@ -600,7 +600,17 @@ def test_automatic_variant_policy(pt, lab, oracle, gpu):
         r.destroy()
     big = pt.Renderer(1024, 1024, 8)
     assert big.kernel_info(9)["variant"] == 6
+    # many-sphere scenes: the grid kernel from 160 spheres on any tile, from 72 on a tile that fills the chip (tools/grid_threshold.py)
+    assert [big.kernel_info(n)["variant"] for n in (11, 71, 72, 159, 160, 2048, 2049)] == [10, 10, 13, 13, 13, 13, 10]
     big.destroy()
+    small = pt.Renderer(128, 128, 8)
+    assert [small.kernel_info(n)["variant"] for n in (71, 72, 159, 160)] == [8, 8, 8, 13]
+    small.destroy()
+    size = 512  # a frame of four one-lane waves per SIMD: the automatic choice for 100 spheres is the grid kernel
+    sph = pt.scene_random(100, seed=41, with_walls=True)
+    basis = pt.camera_basis(width=size, height=size)
+    img, _ = pt.render_frame(size, size, 1, spheres=sph, basis=basis)
+    assert_bit_exact(img, oracle.render(size, size, 1, spheres=sph, basis=basis), "100 spheres, automatic (grid) kernel")
     # Which of variants 6 / 8 / 9 a small scene gets is decided by the cost model (csrc/pt_capi.hip; tests/test_policy_model.py
     # holds it against the measured sweeps): the expectations below are the MODEL's, computed through the lab library, not
     # literals -- row tiles of the headline frame (what a rank of a multi-GPU run renders) and short frames, both generators.
