@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak for the many-sphere kernel (variant 13: grid walk, pooled tests, the sweep): random scenes of 160-2048 spheres -- radii
+"""Soak for the many-sphere kernel (variant 13: grid walk, pooled tests, the sweep): random scenes of 72-2048 spheres -- radii
 from one size to two decades apart, clustered or uniform centres, with or without the walls -- random cameras inside and outside
 the cloud, both generators, 1-8 bounces, frames of complete waves; variant 13 and the automatic choice against the CPU oracle,
 BIT FOR BIT.  Usage: many_soak.py [n_cases=200] [first_seed=0] [large]   (large: frames of 128-256 pixels a side)"""
@@ -15,7 +15,7 @@ sizes = [128, 160, 256] if len(sys.argv) > 3 else [64, 72, 96]
 bad, floats, t0, refused = [], 0, time.time(), 0
 for seed in range(first, first + n_cases):
     rng = np.random.default_rng(1000003 * seed + 17)
-    n = int(rng.choice([160, 200, 300, 500, 800, 1000, 1500, 2048]))
+    n = int(rng.choice([72, 96, 128, 160, 200, 300, 500, 800, 1000, 1500, 2048]))
     walls = bool(rng.integers(0, 2))
     sc = pt.scene_random(n, seed=seed, with_walls=walls)
     k0 = 7 if walls else 0
