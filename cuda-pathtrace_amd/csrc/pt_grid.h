@@ -65,8 +65,10 @@ struct GridHeader {  // 64 bytes, written by build_grid_kernel
   float inv_cs, slack, cx, cy;
   float cz, far2;  // grid centre and (5E)^2: rays starting farther away are not admitted
   uint32_t n_big, n_items;  // n_big: bits 0-15 = spheres outside the grid, bits 16-31 = entries of the pooled walk's table (cells + chained)
+  float r_small, r_big;     // a sphere is registered in the grid iff r_small <= radius <= r_big (pt_primlist.h classifies with the same compare)
+  uint32_t prim_base, pad_; // variant 13: table index of the per-pixel primary-ray lists (behind the room for cells + chained entries)
 };
-static_assert(sizeof(GridHeader) == 64, "GridHeader layout");
+static_assert(sizeof(GridHeader) == 80, "GridHeader layout");
 
 // accel buffer: header | big[kGridMaxBig] u16 | cell_start[kGridMaxCells + 2] u16 | items[kGridMaxItems] u16 | cells[kGridMaxEntries] 2 x u32
 // `cells` (round 4, variant 13) is the cell table in the form the pooled walk reads with ONE ds_read_b64 per visit.  Entry c
@@ -89,21 +91,27 @@ constexpr int kPoolLdsTarget = 80 * 1024;  // per workgroup
 constexpr int kPoolRing = 512;             // ring entries per wave: a round adds at most 64 * 3 * PT_POOL_STEPS to fewer than 64 pending
 constexpr int kPoolWaveBytes = kPoolRing * 4 + 64 * 8 + 64 * 4 + 64 * 4 + 16;  // ring, best keys, runner-up estimates, the sweep's owner list + slot mask
 constexpr int kGridBigGeomBytes = kGridMaxBig * (int)sizeof(float4);
+// Round 5: behind the cells and their chained entries the table holds, per lane of the workgroup, the list of grid spheres the
+// lane's pixel can see along a PRIMARY ray (pt_primlist.h), in the table's own entry format -- two entries: up to five spheres --
+// so that bounce 0 feeds the pooled tests from it and never walks.  Link fields are 13 bits: the lists must end below 8192.
+constexpr int kPrimEntriesPerLane = 2;
+constexpr int kPrimMaxList = 5;  // 2 spheres + link, then up to 3
+constexpr int kPrimEntries = PT_GRID_BLOCK_THREADS * kPrimEntriesPerLane;
 __host__ __device__ inline int grid_max_entries(int n, bool pooled) {
   if (!pooled) return kGridMaxEntries;  // (variant 11 does not stage the table)
   const int fixed = kTablesF4 * (int)sizeof(float4) + (PT_GRID_BLOCK_THREADS / 64) * kPoolWaveBytes + kGridBigGeomBytes +
-                    kGridMaxBig * (int)sizeof(uint16_t) + 32;
+                    kGridMaxBig * (int)sizeof(uint16_t) + 32 + kPrimEntries * 8;
   int avail = kPoolLdsTarget - fixed - n * (int)sizeof(float4);
   if (avail < 8192) avail = 8192;  // (never with n <= kGridMaxSpheres)
   const int e = avail / 8;
-  return e > kGridMaxEntries ? kGridMaxEntries : e;
+  return e > kGridMaxEntries - kPrimEntries ? kGridMaxEntries - kPrimEntries : e;
 }
 
 // LDS image per workgroup: geometry of all n spheres, the geometry of the spheres outside the grid once more (contiguous: no
 // index read on the way to it), then the tables (dword aligned)
 __host__ __device__ inline size_t grid_lds_bytes(int n, bool pooled) {
   const size_t head = (size_t)n * sizeof(float4) + kGridBigGeomBytes + kGridMaxBig * sizeof(uint16_t);
-  if (pooled) return head + (size_t)grid_max_entries(n, true) * 8;
+  if (pooled) return head + (size_t)(grid_max_entries(n, true) + kPrimEntries) * 8;
   return head + (kGridCellsOff - kGridStartOff);
 }
 
@@ -490,6 +498,10 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     h.far2 = far * far;
     h.n_big = n_big | ((ncells + n_ext) << 16);
     h.n_items = total;
+    h.r_small = r_small;
+    h.r_big = r_big;
+    h.prim_base = (uint32_t)max_entries;
+    h.pad_ = 0u;
     *hdr = h;
   }
 }
@@ -622,8 +634,11 @@ struct GridWalk {
   __device__ __forceinline__ bool busy() const { return (k0 < k1) | have_next | walking; }
 };
 
+// `prim` (variant 13, round 5): the ray is a PRIMARY ray of a pixel whose list of visible grid spheres was built before the sample
+// loop (pt_primlist.h).  Such a lane does not walk: the "cell" it starts in is its list (same entry format, links included) and
+// it is marked as having left the grid, so the pooled loop tests the list's spheres and nothing else.
 template <bool POOLED = false>
-__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a) {
+__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a, bool prim = false) {
   const float INF = __builtin_inff();
   const float two_a = 2.0f * a, a4 = 4.0f * a;
   const float Tlim = 1000000.0f * two_a;
@@ -706,9 +721,10 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   w.e0 = 0u, w.e1 = 0u;
   w.k0 = 0u, w.k1 = 0u;
   if constexpr (POOLED) {
-    const uint2 e = G.cells[cidx];
-    w.e0 = active ? e.x : 0u;
+    const uint2 e = G.cells[prim ? G.h.prim_base + (uint32_t)kPrimEntriesPerLane * threadIdx.x : (uint32_t)cidx];
+    w.e0 = (active | prim) ? e.x : 0u;
     w.e1 = e.y;
+    active = active & !prim;
   } else {
     w.k0 = G.cell_start[cidx], w.k1 = G.cell_start[cidx + 1];
     if (!active) w.k1 = w.k0;
@@ -1345,12 +1361,12 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
 // regeneration kernel, where lanes finish at different times) is here to HELP: it draws sphere tests and sweep crossings like
 // everybody else, owns nothing and gets nothing back.
 __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
-                                                            float& t_hit, int& idx, bool walker = true) {
+                                                            float& t_hit, int& idx, bool walker = true, bool prim = false) {
   GridWalk w;
   // (no branch around grid_begin for the helpers: they run it on whatever ray they last had -- the wave executes it anyway -- and
   // their walk is then emptied with selects.  A divergent region that ends here, in front of the register-hungry walk, is where
   // the allocator's split copies landed in front of the exec restore: DESIGN.md A.12.)
-  grid_begin<true>(w, G, o, d, a);
+  grid_begin<true>(w, G, o, d, a, prim & walker);
   const float INF = __builtin_inff();
   w.s.T1 = walker ? w.s.T1 : INF;
   w.s.T2 = walker ? w.s.T2 : INF;
@@ -1364,7 +1380,9 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
 
 // variant 13's nearest-hit search
 // `live` false: a lane without a ray (see intersect_scene_grid_pooled); it returns false and its outputs are not written
-__device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, bool live = true) {
+// `prim`: a primary ray of a pixel with a list (grid_begin)
+__device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, bool live = true,
+                                                    bool prim = false) {
   if (n <= 0) return false;
   const float a = dot(d, d);
   const GridLds& G = *sc.grid;
@@ -1374,7 +1392,7 @@ __device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F
     // (helpers go in only where somebody walks: wave-uniform)
     const bool walk_here = __builtin_amdgcn_ballot_w64(admitted) != 0;
     if (admitted | (walk_here & !live)) {
-      const bool hit = intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx, admitted);
+      const bool hit = intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx, admitted, prim);
       if (admitted) return hit;
     }
   }

@@ -197,20 +197,21 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     dir = lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
   };
 
+  // the primary direction for screen position (sx, sy) in pixel units, by primary_ray's own formula (footprint analyses)
+  auto dir_at = [&](float sx, float sy) {
+    if (pow2_image) {
+      sx *= inv_h;
+      sy *= inv_w;
+    } else {
+      sx /= (float)a.height;
+      sy /= (float)a.width;
+    }
+    return lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
+  };
   if constexpr (REF && VAR == 6) {
 #ifndef PT_NO_FOOTPRINT
     // once per pixel: the spheres this pixel's primary rays can return; the wave ranks the union at bounce 0
     if (a.spp >= PT_FOOTPRINT_MIN_SPP) {
-      auto dir_at = [&](float sx, float sy) {
-        if (pow2_image) {
-          sx *= inv_h;
-          sy *= inv_w;
-        } else {
-          sx /= (float)a.height;
-          sy /= (float)a.width;
-        }
-        return lerp(lerp(B0, B1, sy), lerp(B2, B3, sy), 1.0f - sx);
-      };
       const uint32_t mine = active ? primary_candidates(sc, a.n_spheres, (float)row, (float)col, dir_at) : 0u;
       uint32_t wave_mask = 0u;
 #pragma unroll
@@ -221,6 +222,28 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   }
 
   int i = active ? i_begin : i_end;  // inactive lanes trace nothing ([i_begin, i_end): all samples unless the frame is chunked)
+  bool prim_ok = false;  // variant 13: this pixel's primary rays take their spheres from the pixel's list instead of walking the grid
+  if constexpr (VAR == 13 && PT_PRIMLIST) {
+    // once per pixel and workgroup: the grid spheres the pixel's primary rays can return (pt_primlist.h)
+    if (grid.valid && a.spp >= PT_PRIMLIST_MIN_SPP && a.max_bounces >= 1) {
+      int k = 0;
+      const uint32_t slot = grid.h.prim_base + (uint32_t)kPrimEntriesPerLane * threadIdx.x;
+      prim_ok = build_primary_list(grid, a.spheres, a.n_spheres, eye, (float)row, (float)col, active, dir_at, pool_of_wave(sc.pool).ring,
+                                   const_cast<uint2*>(grid.cells), slot, k);
+      // a pixel that sees nothing at all: every sample is `output.color += color; return` (:157-161) after its jitter draws
+      if (prim_ok & (k == 0) & ((grid.h.n_big & 0xFFFFu) == 0u)) {
+        for (; i < i_end; i++) {
+          if constexpr (RNG == PT_RNG_XORWOW) {  // (philox: begin_sample only positions the counter)
+            if (a.spp != 1) {
+              float jx, jy;
+              rng.jitter(jx, jy);  // :223-224
+            }
+          }
+          L.color = L.color + mk3(0.0f, 0.0f, 0.0f);  // :159
+        }
+      }
+    }
+  }
   if constexpr (kRegen) {
     // Path regeneration (the bit-exact form of active-ray compaction for a kernel whose accumulators are
     // per lane): the sample loop and the bounce loop are flattened into one per-lane state machine, so a
@@ -267,7 +290,8 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       }
       bool escaped = false;
       if (n < a.max_bounces) {
-        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n, live);
+        escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n, live,
+                                                                           live & prim_ok & (n == 0));
         if (live) n++;
       }
       if (live & (escaped | (n >= a.max_bounces))) {

@@ -3,6 +3,7 @@
 #pragma once
 #include "pt_grid.h"
 #include "pt_footprint.h"
+#include "pt_primlist.h"
 
 #pragma clang fp contract(off)
 
@@ -77,14 +78,14 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
 // as a helper of the wave's pooled tests and changes nothing of its own
 template <int RNG, int VAR, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
-                                            Rng<RNG>& rng, Welford (&var)[4], int n, bool live = true) {
+                                            Rng<RNG>& rng, Welford (&var)[4], int n, bool live = true, bool prim = false) {
   float t = 0.0f;
   int idx = 0;
   bool hit;
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
   else if constexpr (VAR == 13)
-    hit = intersect_scene_v13(sc, nsph, o, d, t, idx, live);
+    hit = intersect_scene_v13(sc, nsph, o, d, t, idx, live, prim);  // prim: a primary ray of a pixel with a list (pt_primlist.h)
   else
     hit = intersect_scene<VAR, PRIMARY, LAST>(sc, nsph, o, d, t, idx);
   if (VAR == 13 && !live) return true;
