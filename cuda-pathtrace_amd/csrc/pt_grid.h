@@ -637,8 +637,10 @@ struct GridWalk {
 // `prim` (variant 13, round 5): the ray is a PRIMARY ray of a pixel whose list of visible grid spheres was built before the sample
 // loop (pt_primlist.h).  Such a lane does not walk: the "cell" it starts in is its list (same entry format, links included) and
 // it is marked as having left the grid, so the pooled loop tests the list's spheres and nothing else.
+// `walks` false: a lane that is here only to help (variant 13).  When NO lane of the wave walks -- a closed scene's bounce 0, where
+// every lane is a primary ray with a list -- the clip against the box and the DDA set-up are skipped (wave-uniform branch).
 template <bool POOLED = false>
-__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a, bool prim = false) {
+__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a, bool prim = false, bool walks = true) {
   const float INF = __builtin_inff();
   const float two_a = 2.0f * a, a4 = 4.0f * a;
   const float Tlim = 1000000.0f * two_a;
@@ -668,13 +670,25 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
       }
     }
   }
+  bool active = false;
+  int cidx = 0;
+  float t_out = INF;
+  w.tmax0 = INF, w.tmax1 = INF, w.tmax2 = INF, w.tdel0 = INF, w.tdel1 = INF, w.tdel2 = INF;
+  w.cs0 = 0, w.cs1 = 0, w.cs2 = 0;
+  uint32_t left = 0x20080200u;
+  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(a);
+  bool somebody_walks = true;
+#if PT_V13_SKIP_SETUP
+  if constexpr (POOLED) somebody_walks = __builtin_amdgcn_ballot_w64(walks & !prim) != 0ull;
+#endif
+  if (somebody_walks) {
   // clip against the grid box
   const float gmin[3] = {G.h.ox, G.h.oy, G.h.oz};
   const float dims_f[3] = {(float)G.h.nx, (float)G.h.ny, (float)G.h.nz};
   const int dims[3] = {(int)G.h.nx, (int)G.h.ny, (int)G.h.nz};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   const float tiny = __builtin_amdgcn_sqrtf(a) * 9.094947e-13f;  // 2^-40 |d|
-  float inv[3], t_in = 0.0f, t_out = INF;
+  float inv[3], t_in = 0.0f;
   bool par[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -688,13 +702,8 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
     t_in = fmaxf(t_in, tn);
     t_out = fminf(t_out, tf);
   }
-  const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(a);
-  bool active = (t_in <= t_out + slack_t) & (t_in * two_a < Tlim_hi);
+  active = (t_in <= t_out + slack_t) & (t_in * two_a < Tlim_hi);
   // entry cell and DDA state
-  w.tmax0 = INF, w.tmax1 = INF, w.tmax2 = INF, w.tdel0 = INF, w.tdel1 = INF, w.tdel2 = INF;
-  int cidx = 0;
-  w.cs0 = 0, w.cs1 = 0, w.cs2 = 0;
-  uint32_t left = 0x20080200u;
   const int stride[3] = {1, dims[0], dims[0] * dims[1]};
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -716,6 +725,7 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
     left |= (uint32_t)(fwd ? dims[k] - 1 - ci : ci) << (10 * k);
   }
   cidx = active ? cidx : 0;
+  }
   w.cidx = cidx;
   w.left = left;
   w.e0 = 0u, w.e1 = 0u;
@@ -851,25 +861,45 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
   walk.have_next = have_next, walk.walking = walking;
 }
 
+// `last` (variant 13's regeneration loop, round 5): the caller uses only the hit/miss decision and the index -- the last bounce of
+// a path: emission of the sphere hit, nothing else; t, the hit point and the next ray are dead.  The winner's FP64 exact step is
+// then replaced by its float part and the two certainty tests of intersect_scene_screened_keys' LAST (pt_intersect.h; DESIGN.md
+// A.8 "Last bounce"), in this file's units: estimates are of 2a t and b = 2 d.off, so dacc here is four times dacc there and
+// a4 c four times a c -- exact powers of two on both sides of every compare.  A winner that fails either test goes the usual way.
 __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d,
-                                         float& t_hit, int& idx) {
+                                         float& t_hit, int& idx, bool last = false) {
   const float INF = __builtin_inff();
   const float Tlim = 1000000.0f * (2.0f * w.a);
   const Near2& s = w.s;
   const bool has = s.T1 < INF;
   bool ambiguous = (has & ((s.T2 <= s.T1 * 1.0000038f) | (s.T1 >= Tlim * 0.99998f))) | w.forced;  // (forced: variant 13's round cap)
-  float t;
-  bool bad = false;
-  const RayConst rc = make_ray_const(d);
+  float t = s.T1;  // (last: not a distance -- the caller does not use it)
   const float4 gw = G.geom[s.i1];
-  bool real = intersect_sphere_nb(o, d, rc, gw, t, bad);
-  // the cheap sequences met an input outside their verified domain: the literal test, for the winner alone
-  if (__builtin_expect(has & bad, 0)) real = intersect_sphere(o, d, rc.a, gw, t);
-  const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
-  ambiguous = ambiguous | (has & !good);
-  t_hit = t;
+  bool hit = has;
   idx = s.i1;
-  bool hit = has & good;
+#if PT_V13_LAST_NOEXACT
+  if (last) {
+    const F3 off = mk3(o.x - gw.x, o.y - gw.y, o.z - gw.z);
+    const float b = 2.0f * dot(d, off);
+    const float c = dot(off, off) - gw.w;
+    const float a4 = 4.0f * w.a;
+    const float a4c = a4 * c;
+    const float dacc = fmaf(-a4, c, b * b);
+    const bool certain = (dacc > fabsf(a4c) * 4.7683716e-07f) & (s.T1 >= (2.0f * w.a) * 1e-30f);
+    ambiguous = ambiguous | (has & !certain);
+  } else
+#endif
+  {
+    bool bad = false;
+    const RayConst rc = make_ray_const(d);
+    bool real = intersect_sphere_nb(o, d, rc, gw, t, bad);
+    // the cheap sequences met an input outside their verified domain: the literal test, for the winner alone
+    if (__builtin_expect(has & bad, 0)) real = intersect_sphere(o, d, rc.a, gw, t);
+    const bool good = real & (t >= kMinGoodT) & (t < 1000000.0f);  // (quotient_to_float_nb relies on this range test)
+    ambiguous = ambiguous | (has & !good);
+    hit = has & good;
+  }
+  t_hit = t;
   PT_STAT(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(ambiguous)));
 #ifdef PT_GRID_STATS_AMBIG  // why lanes are ambiguous (tools/grid_stats.py ambig): slots 1-4 and 7 re-used
   PT_STAT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & (s.T2 <= s.T1 * 1.0000038f))));
@@ -878,7 +908,7 @@ __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, 
   PT_STAT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(has & !good)));
 #endif
 #ifndef PT_TIMING_ONLY_NO_AMBIG  // never defined in a shipped build: what the literal redo of ambiguous lanes costs
-  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, rc, t_hit, idx);
+  if (__builtin_expect(ambiguous, 0)) hit = intersect_scene_loop<0>(sc, n, o, d, make_ray_const(d), t_hit, idx);
 #endif
   return hit;
 }
@@ -947,6 +977,12 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 // Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
 // expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
 // (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
+#ifndef PT_V13_SKIP_SETUP
+#define PT_V13_SKIP_SETUP 1    // grid_begin: no clip / DDA set-up when no lane of the wave walks
+#endif
+#ifndef PT_V13_LAST_NOEXACT
+#define PT_V13_LAST_NOEXACT 1  // grid_end: a path's last bounce confirms its winner without the FP64 exact step
+#endif
 #ifndef PT_POOL_STEPS
 #define PT_POOL_STEPS 2
 #endif
@@ -1361,12 +1397,13 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
 // regeneration kernel, where lanes finish at different times) is here to HELP: it draws sphere tests and sweep crossings like
 // everybody else, owns nothing and gets nothing back.
 __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d, float a,
-                                                            float& t_hit, int& idx, bool walker = true, bool prim = false) {
+                                                            float& t_hit, int& idx, bool walker = true, bool prim = false,
+                                                            bool last = false) {
   GridWalk w;
   // (no branch around grid_begin for the helpers: they run it on whatever ray they last had -- the wave executes it anyway -- and
   // their walk is then emptied with selects.  A divergent region that ends here, in front of the register-hungry walk, is where
   // the allocator's split copies landed in front of the exec restore: DESIGN.md A.12.)
-  grid_begin<true>(w, G, o, d, a, prim & walker);
+  grid_begin<true>(w, G, o, d, a, prim & walker, walker);
   const float INF = __builtin_inff();
   w.s.T1 = walker ? w.s.T1 : INF;
   w.s.T2 = walker ? w.s.T2 : INF;
@@ -1375,14 +1412,15 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
   w.e1 = walker ? w.e1 : 0u;
   grid_trips_pooled(w, G, pool_of_wave(sc.pool), o, d);
   if (!walker) return false;
-  return grid_end(w, sc, G, n, o, d, t_hit, idx);
+  return grid_end(w, sc, G, n, o, d, t_hit, idx, last);
 }
 
 // variant 13's nearest-hit search
 // `live` false: a lane without a ray (see intersect_scene_grid_pooled); it returns false and its outputs are not written
 // `prim`: a primary ray of a pixel with a list (grid_begin)
+// `last`: only hit/miss and the index are wanted (grid_end)
 __device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F3 o, F3 d, float& t_hit, int& idx, bool live = true,
-                                                    bool prim = false) {
+                                                    bool prim = false, bool last = false) {
   if (n <= 0) return false;
   const float a = dot(d, d);
   const GridLds& G = *sc.grid;
@@ -1392,7 +1430,7 @@ __device__ __forceinline__ bool intersect_scene_v13(const SceneLds& sc, int n, F
     // (helpers go in only where somebody walks: wave-uniform)
     const bool walk_here = __builtin_amdgcn_ballot_w64(admitted) != 0;
     if (admitted | (walk_here & !live)) {
-      const bool hit = intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx, admitted, prim);
+      const bool hit = intersect_scene_grid_pooled(sc, G, n, o, d, a, t_hit, idx, admitted, prim, last);
       if (admitted) return hit;
     }
   }

@@ -87,6 +87,9 @@
 #ifndef PT_POOL_HELPERS
 #define PT_POOL_HELPERS 1  // variant 13: lanes whose pixel is finished stay in the loop as helpers of the wave's pooled sphere tests (pt_kernel.hip)
 #endif
+#ifndef PT_V13_DEAD_END
+#define PT_V13_DEAD_END 1  // variant 13: the last bounce of a path forms no next ray and skips the winner's FP64 step (pt_trace.h, pt_grid.h)
+#endif
 #ifndef PT_POOL_MIN_WAVES
 // variant 13 (variant 11 with the sphere tests pooled across the wave, pt_grid.h) is issue-bound, not latency-bound like its
 // predecessor: four waves per SIMD with 128 registers and no spills beat six with 80 and 128 B of scratch (13.9 -> 13.3 ms)

@@ -290,8 +290,10 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
       }
       bool escaped = false;
       if (n < a.max_bounces) {
+        // (variant 13: a path's last bounce -- never its first -- needs neither the hit distance nor a next ray: pt_trace.h, pt_grid.h)
+        const bool dead_end = VAR == 13 && PT_V13_DEAD_END && (n > 0) & (n == a.max_bounces - 1);
         escaped = !bounce_once<RNG, (VAR == 11 ? 11 : VAR == 13 ? 13 : 6)>(L, sc, a.n_spheres, o, d, color, mask, rng, var, n, live,
-                                                                           live & prim_ok & (n == 0));
+                                                                           live & prim_ok & (n == 0), dead_end);
         if (live) n++;
       }
       if (live & (escaped | (n >= a.max_bounces))) {

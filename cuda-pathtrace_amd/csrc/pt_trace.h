@@ -14,9 +14,11 @@ namespace pt {
 // PRIMARY (only ever with n == 0): o is the eye the scene image was staged for, see SceneLds::eyeg
 // (bounce_once = the nearest-hit search + bounce_shade; variant 12 runs the two at different times)
 // the part of the iteration after intersectScene (:156): hit/t/idx are its results
+// `dead_end` (variant 13's regeneration loop; never with n == 0): the path ends after this iteration, so the next ray is not
+// formed -- the generator still makes its two draws (:131), which is all of :176-180 that outlives the iteration
 template <int RNG, int VAR>
 __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc, F3& o, F3& d, F3& color, F3& mask,
-                                             Rng<RNG>& rng, Welford (&var)[4], int n, bool hit, float t, int idx) {
+                                             Rng<RNG>& rng, Welford (&var)[4], int n, bool hit, float t, int idx, bool dead_end = false) {
   if (!hit) {  // :157-161
     L.color = L.color + color;
     return false;
@@ -25,20 +27,22 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
   F3 emis, scol;
   float lum_col = 0.0f;
   fetch_material(sc, idx, emis, scol, n == 0 ? &lum_col : nullptr);
-  F3 normal;
+  F3 normal = mk3(0.0f, 0.0f, 0.0f);
   float u_az, u_el;
   if constexpr (VAR >= 6) {
     // whole geometric step speculatively with the cheap sequences, literal redo if any of them
     // met an input outside its verified domain (never observed in the Cornell box)
     rng.bounce(n, u_az, u_el);
-    bool bad = false;
-    BounceGeom bg = bounce_geometry<true, true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad, sc.inv1, sc.absmask);
+    if (!dead_end) {
+      bool bad = false;
+      BounceGeom bg = bounce_geometry<true, true>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad, sc.inv1, sc.absmask);
 #ifndef PT_TIMING_ONLY_NO_SHADE_REDO
-    if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
+      if (__builtin_expect(bad, 0)) bg = bounce_geometry<false>(o, d, t, mk3(g.x, g.y, g.z), u_az, u_el, bad);
 #endif
-    normal = bg.normal;
-    o = bg.o;
-    d = bg.d;
+      normal = bg.normal;
+      o = bg.o;
+      d = bg.d;
+    }
   } else {
     F3 pos = o + d * t;                                // :163
     normal = pos - mk3(g.x, g.y, g.z);                 // :164
@@ -78,18 +82,19 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
 // as a helper of the wave's pooled tests and changes nothing of its own
 template <int RNG, int VAR, bool PRIMARY = false, bool LAST = false>
 __device__ __forceinline__ bool bounce_once(TraceOutput& L, const SceneLds& sc, int nsph, F3& o, F3& d, F3& color, F3& mask,
-                                            Rng<RNG>& rng, Welford (&var)[4], int n, bool live = true, bool prim = false) {
+                                            Rng<RNG>& rng, Welford (&var)[4], int n, bool live = true, bool prim = false,
+                                            bool dead_end = false) {
   float t = 0.0f;
   int idx = 0;
   bool hit;
   if constexpr (VAR == 11)
     hit = intersect_scene_v11(sc, nsph, o, d, t, idx);
   else if constexpr (VAR == 13)
-    hit = intersect_scene_v13(sc, nsph, o, d, t, idx, live, prim);  // prim: a primary ray of a pixel with a list (pt_primlist.h)
+    hit = intersect_scene_v13(sc, nsph, o, d, t, idx, live, prim, dead_end);  // prim: a primary ray of a pixel with a list (pt_primlist.h)
   else
     hit = intersect_scene<VAR, PRIMARY, LAST>(sc, nsph, o, d, t, idx);
   if (VAR == 13 && !live) return true;
-  return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx);
+  return bounce_shade<RNG, VAR>(L, sc, o, d, color, mask, rng, var, n, hit, t, idx, dead_end);
 }
 
 // trace_ray: src/pathtrace.cu:150-201

@@ -38,7 +38,7 @@ def pmc(sub):
     return {k: med(v) for k, v in acc.items()}, {k: v for k, v in acc.items() if k in ("FETCH_SIZE", "WRITE_SIZE")}
 
 counters = {}
-for sub in ("pmc_sq", "pmc_sq2", "pmc_mix1", "pmc_mix2", "pmc_write", "pmc_fetch"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_mix1", "pmc_mix2", "pmc_write", "pmc_fetch"):
     c, n = pmc(sub)
     counters.update(c)
     if n:
