@@ -126,6 +126,12 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
 // emission and colour of sphere idx (Scene.h:10-11) from whichever copy the layout keeps
 __device__ __forceinline__ void fetch_material(const SceneLds& sc, int idx, F3& emis, F3& scol, float* lum_col = nullptr) {
   if (sc.lean) {
+#ifdef PT_TIMING_ONLY_NO_MATERIAL  // never defined in a shipped build: what the per-bounce gather from global memory costs
+    emis = mk3(0.0f, 0.0f, 0.0f);
+    scol = mk3(0.5f, 0.5f, 0.5f);
+    if (lum_col) *lum_col = 0.5f;
+    return;
+#endif
     const pt_sphere* sp = sc.global + idx;
     emis = mk3(sp->emission[0], sp->emission[1], sp->emission[2]);
     scol = mk3(sp->color[0], sp->color[1], sp->color[2]);
