@@ -208,23 +208,51 @@ def other_configs(pt, torch, device, stream, rng_mode):
             # the reference's loop body is Render THEN Denoise (main.cu:148,175): the same stream of frames with the display pack
             # as a second launch per frame, and with the pack fused into the render kernel (pt_renderer_set_display)
             vtx = torch.empty(h * w * 3, dtype=torch.float32, device=device)
-            walls = {}
-            for mode in ("separate", "fused"):
-                r.set_display(vtx.data_ptr() if mode == "fused" else None)
-                for rep in range(reps + warm):
-                    if rep == warm:
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                    r.enqueue(frame.data_ptr(), d_scene.data_ptr(), len(sph), basis, pt.DEFAULT_EYE, stream=stream.cuda_stream)
-                    if mode == "separate":
-                        pt.check(pt.lib.pt_display_pack(frame.data_ptr(), w, h, vtx.data_ptr(), stream.cuda_stream))
-                torch.cuda.synchronize()
-                walls[mode] = (time.perf_counter() - t1) / reps * 1e3
+            # Protocol (one 200-frame window per mode could not tell a host stall from a slow kernel): the two modes
+            # ALTERNATE, five windows of 1000 frames each, one perf_counter pair per window; min / median / max over the windows
+            # are reported per mode, and beside them the KERNEL milliseconds of 20 frames per window from events on the launch
+            # stream (render, or render + pack).  A stalled host shows as max >> median with the kernel time unchanged.
+            n_win, n_frames, n_ev = 5, 1000, 20
+            walls = {"separate": [], "fused": []}
+            kern = {"separate": [], "fused": []}
+
+            def one_frame(mode):
+                r.enqueue(frame.data_ptr(), d_scene.data_ptr(), len(sph), basis, pt.DEFAULT_EYE, stream=stream.cuda_stream)
+                if mode == "separate":
+                    pt.check(pt.lib.pt_display_pack(frame.data_ptr(), w, h, vtx.data_ptr(), stream.cuda_stream))
+
+            for win in range(n_win):
+                for mode in ("separate", "fused"):
+                    r.set_display(vtx.data_ptr() if mode == "fused" else None)
+                    for _ in range(warm):
+                        one_frame(mode)
+                    torch.cuda.synchronize()
+                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+                    t1 = time.perf_counter()
+                    for k in range(n_frames):
+                        sample = k % (n_frames // n_ev) == 0 and k // (n_frames // n_ev) < n_ev
+                        if sample:
+                            evs[k // (n_frames // n_ev)][0].record(stream)
+                        one_frame(mode)
+                        if sample:
+                            evs[k // (n_frames // n_ev)][1].record(stream)
+                    torch.cuda.synchronize()
+                    walls[mode].append((time.perf_counter() - t1) / n_frames * 1e3)
+                    kern[mode] += [a.elapsed_time(b) for a, b in evs]
             r.set_display(None)
-            display = {"render_plus_pack_launch_ms_per_frame": round(walls["separate"], 4),
-                       "render_with_fused_pack_ms_per_frame": round(walls["fused"], 4),
-                       "note": "Denoiser::Denoise (display vertices, 12 B per pixel) after every frame: as its own launch, and fused into the "
-                               "render kernel's epilogue (pt_renderer_set_display); wall ms per frame in a stream of frames"}
+
+            def mmm(v):
+                v = sorted(v)
+                return {"min": round(v[0], 4), "median": round(v[len(v) // 2], 4), "max": round(v[-1], 4)}
+
+            display = {"render_plus_pack_launch_ms_per_frame": mmm(walls["separate"])["median"],
+                       "render_with_fused_pack_ms_per_frame": mmm(walls["fused"])["median"],
+                       "windows": {"count": n_win, "frames_each": n_frames, "order": "separate, fused alternating"},
+                       "wall_ms_per_frame": {"separate": mmm(walls["separate"]), "fused": mmm(walls["fused"])},
+                       "kernel_ms_per_frame": {"separate": mmm(kern["separate"]), "fused": mmm(kern["fused"])},
+                       "note": "Denoiser::Denoise (display vertices, 12 B per pixel) after every frame (main.cu:148,175): as its own launch, and "
+                               "fused into the render kernel's epilogue (pt_renderer_set_display); wall ms per frame in streams of frames, "
+                               "kernel ms from events around sampled frames (separate: render + pack)"}
             del vtx
         r.destroy()
         samples = w * h * spp
