@@ -378,6 +378,10 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
         want13 = rounds >= 32 ? 1 : (int)((32 + rounds - 1) / rounds);
         if (want13 > 8) want13 = 8;
         while (want13 >= 2 && r->spp / want13 < 32) want13 /= 2;
+        // Round 5: a tile whose workgroups fill at most HALF the chip's slots gains nothing from chunk workgroups -- they are resident
+        // at once and only wait for their predecessors, in slots the working ones could have had to themselves (rows 512..640 of
+        // the 1000-sphere frame, closed / open: 8 chunks 29.1 / 19.1 ms, none 17.9 / 10.4; profiles/r05/cfg4_tile_chunks.txt)
+        if (groups * 2u <= resident) want13 = 1;
       }
       r->chunks13 = fit_chunks(want13, r->spp, PT_CHUNK_MAX_SAMPLES_GRID);
     }
