@@ -254,6 +254,37 @@ def other_configs(pt, torch, device, stream, rng_mode):
                                "fused into the render kernel's epilogue (pt_renderer_set_display); wall ms per frame in streams of frames, "
                                "kernel ms from events around sampled frames (separate: render + pack)"}
             del vtx
+            # the same frames when their cameras are known in advance (a scripted fly-through, a pose sweep): one launch per 32
+            # frames (pt_renderer_enqueue_frames) against the stream of single-frame launches, both into 256 separate frame buffers
+            import numpy as np
+
+            nb = 256
+            big = torch.empty(nb * h * w * 14, dtype=torch.float32, device=device)
+            bases = np.tile(np.asarray(basis, dtype=np.float32).reshape(1, 12), (nb, 1))
+            eyes = np.tile(np.asarray(pt.DEFAULT_EYE, dtype=np.float32).reshape(1, 3), (nb, 1))
+            frames_batch = {"frames": nb, "windows": 5,
+                            "note": "pt_renderer_enqueue_frames, one launch per 32 frames, against the stream of single-frame launches, both into 256 "
+                                    "separate frame buffers; wall ms per frame.  xorwow: a workgroup keeps its pixels and loops over the frames, the "
+                                    "generator stays in registers; philox (re-keyed per frame): one workgroup per (frame, pixel block).  Every frame "
+                                    "bit-identical to the single-frame path (tests/test_frames_gpu.py)"}
+            for gen_name, gen in (("xorwow", pt.RNG_XORWOW), ("philox", pt.RNG_PHILOX)):
+                rb = pt.Renderer(w, h, spp, rng_mode=gen, persist_rng=True, max_bounces=mb)
+                bw = {"single": [], "batched": []}
+                for win in range(5):
+                    for mode in ("single", "batched"):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        if mode == "batched":
+                            rb.enqueue_frames(big.data_ptr(), h * w * 14, d_scene.data_ptr(), len(sph), bases, eyes, stream=stream.cuda_stream)
+                        else:
+                            for f in range(nb):
+                                rb.enqueue(big.data_ptr() + f * h * w * 56, d_scene.data_ptr(), len(sph), basis, pt.DEFAULT_EYE, stream=stream.cuda_stream)
+                        torch.cuda.synchronize()
+                        bw[mode].append((time.perf_counter() - t1) / nb * 1e3)
+                rb.check(wait=True)
+                rb.destroy()
+                frames_batch[gen_name] = {"single_launches_ms_per_frame": mmm(bw["single"]), "one_launch_per_32_frames_ms_per_frame": mmm(bw["batched"])}
+            del big
         r.destroy()
         samples = w * h * spp
         out[key] = {"workload": f"{label} {w}x{h}, {spp} spp, max_bounces {mb} ({c['name']})", "frames": reps,
@@ -264,6 +295,7 @@ def other_configs(pt, torch, device, stream, rng_mode):
                     "hbm_algorithmic_GBps": round(56 * w * h / (kms[len(kms) // 2] * 1e-3) / 1e9, 2)}
         if display:
             out[key]["display"] = display
+            out[key]["frame_batches"] = frames_batch
         del frame, d_scene
     return out
 

@@ -108,6 +108,7 @@ ABI = {
     "pt_renderer_destroy": (ctypes.c_int, [_vp]),
     "pt_renderer_render": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _fp]),
     "pt_renderer_enqueue": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _fp, _fp, _vp]),
+    "pt_renderer_enqueue_frames": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_int, _fp, _fp, _vp]),
     "pt_renderer_check": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
     "pt_renderer_set_display": (ctypes.c_int, [_vp, _vp]),
     "pt_renderer_set_frame": (ctypes.c_int, [_vp, ctypes.c_uint32]),
@@ -386,6 +387,14 @@ class Renderer:
         _, b = _f32(basis, 12)
         _, e = _f32(eye, 3)
         check(lib.pt_renderer_enqueue(self.handle, d_out, d_spheres, n_spheres, b, e, stream))
+
+    def enqueue_frames(self, d_out, out_stride_floats, d_spheres, n_spheres, bases, eyes, d_vertices=None, vtx_stride_floats=0, stream=None):
+        """n frames of known cameras (bases [n][12], eyes [n][3]) into d_out + f * out_stride_floats: pt_renderer_enqueue_frames."""
+        bases = np.ascontiguousarray(bases, dtype=np.float32).reshape(-1, 12)
+        eyes = np.ascontiguousarray(eyes, dtype=np.float32).reshape(-1, 3)
+        assert len(bases) == len(eyes)
+        check(lib.pt_renderer_enqueue_frames(self.handle, len(bases), d_out, out_stride_floats, d_vertices, vtx_stride_floats, d_spheres,
+                                             n_spheres, bases.ctypes.data_as(_fp), eyes.ctypes.data_as(_fp), stream))
 
     def check(self, wait=True):
         """Status of the frames enqueued so far (raises PtError(PT_EKERNEL) for a frame whose sample-chunk chain broke);

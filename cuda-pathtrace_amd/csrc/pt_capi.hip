@@ -592,6 +592,60 @@ int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres
   return PT_OK;
 }
 
+// A batch of frames with known cameras (include/ptcore.h).  Where a frames kernel exists -- the reference's scene in the
+// reference configuration, i.e. the interactive shape -- the batch goes out as launches of up to PT_FRAMES_MAX frames each;
+// everywhere else, and whenever two frames would share a buffer, it is the loop of single-frame enqueues it stands for.
+int pt_renderer_enqueue_frames(pt_renderer* r, int n_frames, float* d_out, size_t out_stride_floats, float* d_vertices,
+                               size_t vtx_stride_floats, const pt_sphere* d_spheres, int n_spheres, const float* bases,
+                               const float* eyes, void* hip_stream) {
+  if (!r) return pt_fail(PT_EINVAL, "pt_renderer_enqueue_frames: renderer is NULL");
+  if (n_frames < 0 || (n_frames > 0 && (!bases || !eyes))) return pt_fail(PT_EINVAL, "pt_renderer_enqueue_frames: bad arguments");
+  if (n_frames == 0) return PT_OK;
+  float* const saved_vertices = r->d_vertices;
+  const size_t tile_floats = (size_t)r->tile_pixels * 14u, vtx_floats = (size_t)r->tile_pixels * 3u;
+  const int variant = effective_variant(r, n_spheres);
+  const bool batched = n_frames >= 2 && r->tile_pixels > 0 && variant != PT_VARIANT_FAST &&
+                       pt_kernel_has_frames(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR) &&
+                       out_stride_floats >= tile_floats && (d_vertices ? vtx_stride_floats >= vtx_floats : saved_vertices == nullptr);
+  int rc = PT_OK;
+  for (int f0 = 0; f0 < n_frames && rc == PT_OK;) {
+    const int m = batched ? (n_frames - f0 < PT_FRAMES_MAX ? n_frames - f0 : PT_FRAMES_MAX) : 1;
+    float* out_f = d_out ? d_out + (size_t)f0 * out_stride_floats : nullptr;
+    if (d_vertices) r->d_vertices = d_vertices + (size_t)f0 * vtx_stride_floats;
+    if (m < 2) {
+      rc = pt_renderer_enqueue(r, out_f, d_spheres, n_spheres, bases + 12 * (size_t)f0, eyes + 3 * (size_t)f0, hip_stream);
+      f0 += 1;
+      continue;
+    }
+    FramesKernelArgs fa;
+    rc = check_device_error(r, false);
+    if (rc != PT_OK) break;
+    rc = fill_args(r, out_f, d_spheres, n_spheres, bases + 12 * (size_t)f0, eyes + 3 * (size_t)f0, &fa.base);
+    if (rc != PT_OK) break;
+    fa.base.chunks = 0u;  // (a batch's workgroups keep their pixel block: nothing is handed from workgroup to workgroup)
+    fa.base.chunk_state = nullptr;
+    fa.base.chunk_flag = nullptr;
+    fa.frames = (uint32_t)m;
+    fa.out_stride = out_stride_floats;
+    fa.vtx_stride = vtx_stride_floats;
+    for (int k = 0; k < m; k++) {
+      memcpy(fa.cams[k], bases + 12 * (size_t)(f0 + k), 12 * sizeof(float));
+      memcpy(fa.cams[k] + 12, eyes + 3 * (size_t)(f0 + k), 3 * sizeof(float));
+    }
+    rc = order_after_last(r, (hipStream_t)hip_stream);
+    if (rc != PT_OK) break;
+    {
+      const hipError_t e = pt_launch_frames_kernel(fa, r->opts.rng_mode, (hipStream_t)hip_stream);
+      if (e != hipSuccess) { rc = pt_fail(PT_EHIP, "pt_renderer_enqueue_frames: %s", hipGetErrorString(e)); break; }
+    }
+    rc = mark_last(r, (hipStream_t)hip_stream);
+    r->frame += (uint32_t)m;
+    f0 += m;
+  }
+  r->d_vertices = saved_vertices;
+  return rc;
+}
+
 int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres, const float basis[12],
                        const float eye[3], float* ms_out) {
   PixelKernelArgs a;

@@ -139,6 +139,16 @@ struct PixelKernelArgs {
   uint32_t repair;             // != 0: repair launch after a broken chunk chain -- unchunked, and pixel blocks whose chunk_flag equals
                                // this value (= the chunk count of the broken launch: complete) are skipped
 };
+// A batch of frames in one launch (pt_renderer_enqueue_frames): the single-frame arguments plus, per frame, the camera
+// (basis[12], eye[3]) and where the frame goes.  At most PT_FRAMES_MAX frames per launch (the argument segment is 4 KB).
+#define PT_FRAMES_MAX 32
+struct FramesKernelArgs {
+  PixelKernelArgs base;        // out / vertices: frame 0's; frame: frame 0's number (philox key)
+  uint32_t frames;             // 2 .. PT_FRAMES_MAX
+  uint64_t out_stride;         // floats from one frame's buffer to the next one's
+  uint64_t vtx_stride;         // ... of the display vertices (fused display pack)
+  float cams[PT_FRAMES_MAX][15];
+};
 // words handed from one chunk of a pixel block to the next: 10 sums, 2 counts (colour; the three first-hit accumulators share
 // one), 4 x {mean, M2}, and the 6 generator words (xorwow only; philox needs none)
 #define PT_CHUNK_WORDS 26
@@ -177,6 +187,9 @@ const void* pt_kernel_symbol(int rng_mode, int variant, int n_spheres, int max_b
 size_t pt_kernel_lds_bytes(int n_spheres, int variant);
 int pt_kernel_max_spheres(int variant);
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream);
+// frame batches: is there a kernel for these launch parameters (reference scene, variant 6, interleaved layout), and the launch
+bool pt_kernel_has_frames(int variant, int n_spheres, int max_bounces, bool planar);
+hipError_t pt_launch_frames_kernel(const FramesKernelArgs& fa, int rng_mode, hipStream_t stream);
 hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */,
                                 bool pooled /* for variant 13's LDS image (fewer cells at large n) */, hipStream_t stream);
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11

@@ -83,10 +83,56 @@ __device__ __forceinline__ void chunk_publish(const PixelKernelArgs& a, uint32_t
   }
 }
 
-template <int RNG, int VAR, bool LEAN = false, int REFB = 0>
-__global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR pixel_kernel(PixelKernelArgs a) {
+// FRAMES (round 5, pt_launch_frames_kernel below): the launch renders a BATCH of frames with known cameras (which travel as
+// kernel arguments too), each into its own buffer, starting from zeroed sums.  Per pixel the operations and their order are those
+// of fr_count single-frame launches.  What links two frames is the generator (the reference's d_states carries every pixel's
+// XORWOW state from one Render() to the next: pathtrace.cu:212,256), hence two shapes:
+//  * XORWOW: a workgroup keeps its pixel block for the whole batch and LOOPS over the frames; the generator simply stays in
+//    its registers.  What goes is the ramp and tail of fr_count launches, the per-launch staging and the state traffic.  (First
+//    built as one workgroup per (frame, block) with the state handed on through the sample chunks' flags: a workgroup that
+//    becomes resident while its predecessor still runs only waits, and the dispatcher cannot pass it over for one that is
+//    ready -- 0.1145 ms per frame against 0.097 as single launches; profiles/r05/cfg5_frames.txt.)
+//  * the counter-based generator is re-keyed per frame, so its frames are independent: one workgroup per (frame, pixel block),
+//    frame-major -- the next frame's workgroups fill the slots the current one's leave (and the fifth slot per CU a single
+//    1024-workgroup frame cannot use).
+template <bool FRAMES> struct KernelArgsOf { typedef PixelKernelArgs type; };
+template <> struct KernelArgsOf<true> { typedef FramesKernelArgs type; };  // (the cameras travel as kernel arguments too)
+template <bool FRAMES> __device__ __forceinline__ PixelKernelArgs& base_args(typename KernelArgsOf<FRAMES>::type& args) {
+  if constexpr (FRAMES) return args.base; else return args;
+}
+
+template <int RNG, int VAR, bool LEAN = false, int REFB = 0, bool FRAMES = false>
+__global__ void __launch_bounds__(kBlockThreads<VAR>, ((FRAMES && RNG == PT_RNG_XORWOW) ? PT_MIN_WAVES : kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR
+pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch has one workgroup per pixel block for all its frames: the
+                                                           // interactive shape fills four of a CU's five slots, so that build takes 128 registers)
+  PixelKernelArgs& a = base_args<FRAMES>(args);
+  // a batch of frames, two shapes (head of this section): the counter-based generator's frames are independent -- one workgroup
+  // per (frame, pixel block), frame-major; XORWOW's are a chain per pixel -- one workgroup per pixel block, looping over the frames
+  constexpr bool FRAME_GRID = FRAMES && RNG == PT_RNG_PHILOX, FRAME_LOOP = FRAMES && !FRAME_GRID;
+  uint32_t fr = 0u, fr_count = 1u, first_block = blockIdx.x;
+  auto load_camera = [&](uint32_t f) {
+    if constexpr (FRAMES) {
+      // by scalar loads from the argument segment itself (indexing the by-value struct with a run-time index would make the
+      // compiler copy all of it to scratch memory)
+      typedef const __attribute__((address_space(4))) float* cfloats;
+      typedef const __attribute__((address_space(4))) char* cbytes;
+      const cfloats cam = (cfloats)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FramesKernelArgs, cams)) + 15u * f;
+#pragma unroll
+      for (int k = 0; k < 12; k++) a.basis[k] = cam[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) a.eye[k] = cam[12 + k];
+    }
+  };
+  if constexpr (FRAMES) fr_count = args.frames;
+  if constexpr (FRAME_GRID) {
+    const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
+    fr = blockIdx.x / n_blocks;  // (workgroup-uniform)
+    first_block = blockIdx.x - fr * n_blocks;
+    load_camera(fr);  // before the scene image is staged for this frame's eye
+  }
   constexpr bool REF = REFB != 0;
-  constexpr bool CHUNKS = kChunkable<VAR, REFB>;
+  constexpr bool CHUNKS = kChunkable<VAR, REFB> && !FRAMES;
+  static_assert(!FRAMES || (VAR == 6 && REFB != 0), "frame batches: reference-configuration builds of variant 6");
   if constexpr (REF) {
     a.n_spheres = 9;
     a.max_bounces = REFB;
@@ -118,7 +164,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
   // model, so the wait is bounded in time and giving up raises the renderer's error word (PT_EKERNEL), never a silent frame.
   // Same operations per pixel in the same order; what changes is that a frame of few, long workgroups becomes one of many
   // short ones (tools/shape_sweep.py: why).
-  uint32_t block_id = blockIdx.x, chunk = 0u, n_chunks = 1u;
+  uint32_t block_id = FRAMES ? first_block : blockIdx.x, chunk = 0u, n_chunks = 1u;
   if constexpr (CHUNKS) {
     if (a.chunks > 1u) {
       const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
@@ -147,11 +193,28 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     rng.pix = id;
   }
 
+  const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
+  const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
+
+  // (the frame loop of a batch is a backward goto that exists in the FRAME_LOOP builds only: every other build's code is,
+  // instruction for instruction, what it was without it -- a `for` with one trip was not, and the headline kernel's allocation is touchy)
+frame_top:
+  if constexpr (FRAME_LOOP) {
+    load_camera(fr);
+    if (fr > 0u) {  // the scene image's eye part (SceneLds::eyeg: off and c of :73,76 for rays from THIS frame's eye), as stage_scene forms it
+      __syncthreads();  // every wave has finished the previous frame's primary rays
+      for (int i = threadIdx.x; i < a.n_spheres; i += blockDim.x) {
+        const float4 g = sc.geom[i];
+        const F3 off = mk3(a.eye[0] - g.x, a.eye[1] - g.y, a.eye[2] - g.z);
+        sc.eyeg[i] = make_float4(off.x, off.y, off.z, dot(off, off) - g.w);
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (FRAMES && RNG == PT_RNG_PHILOX) rng.k1 = (uint32_t)(a.seed >> 32) ^ (a.frame + fr);
   const F3 B0 = mk3(a.basis[0], a.basis[1], a.basis[2]), B1 = mk3(a.basis[3], a.basis[4], a.basis[5]);
   const F3 B2 = mk3(a.basis[6], a.basis[7], a.basis[8]), B3 = mk3(a.basis[9], a.basis[10], a.basis[11]);
   const F3 eye = mk3(a.eye[0], a.eye[1], a.eye[2]);
-  const bool pow2_image = ((a.width & (a.width - 1)) == 0) && ((a.height & (a.height - 1)) == 0);  // wave-uniform
-  const float inv_w = 1.0f / (float)a.width, inv_h = 1.0f / (float)a.height;  // exact for powers of two
 
   Welford var[4] = {{0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}, {0, 0.0f, 0.0f}};
   TraceOutput L{mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f};
@@ -459,7 +522,13 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
                         L.normal.z / fs, L.albedo.x / fs, L.albedo.y / fs, L.albedo.z / fs, L.depth / fs,
                         welford_variance(var[0]), welford_variance(var[1]), welford_variance(var[2]),
                         welford_variance(var[3])};  // :240-254
-  if (a.vertices && active) store_display_vertex(a.vertices + (size_t)tp * 3, a.width, row, col, px[0], px[1], px[2]);
+  float* out_f = a.out;  // this frame's buffers
+  float* vtx_f = a.vertices;
+  if constexpr (FRAMES) {
+    out_f += (size_t)fr * args.out_stride;
+    if (vtx_f) vtx_f += (size_t)fr * args.vtx_stride;
+  }
+  if (vtx_f && active) store_display_vertex(vtx_f + (size_t)tp * 3, a.width, row, col, px[0], px[1], px[2]);
   // The 64 pixels of a wave are 64 consecutive columns, so their 64 x 14 floats are ONE contiguous
   // 3584-byte span of the [row][col][14] buffer: transpose through the wave's own LDS slice and write
   // it as 224 coalesced 16-byte stores (3.5 per lane) instead of 14 strided dword stores per lane.
@@ -467,11 +536,11 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     // (the reference-configuration builds are interleaved-only: the launcher sends planar frames to the generic build)
     if (active) {
 #pragma unroll
-      for (int c = 0; c < 14; c++) a.out[(size_t)c * a.tile_pixels + tp] = px[c];
+      for (int c = 0; c < 14; c++) out_f[(size_t)c * a.tile_pixels + tp] = px[c];
     }
   } else {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0u) &&
+  const bool wave_full = (__builtin_amdgcn_ballot_w64(active) == ~0ull) && ((reinterpret_cast<uintptr_t>(out_f) & 15u) == 0u) &&
                          VAR != 11 && VAR != 12 && VAR != 13;  // variants 11-13: the LDS holds the grid until the last wave is done: plain stores there
   if (wave_full) {
     float* wl = reinterpret_cast<float*>(lds_scene + a.scene_lds_f4) + wave * (64 * 14);
@@ -479,17 +548,21 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     for (int c = 0; c < 14; c++) wl[lane * 14 + c] = px[c];
     __builtin_amdgcn_wave_barrier();  // DS operations of one wave execute in order: the reads below see these writes
     const float4* src = reinterpret_cast<const float4*>(wl);
-    float4* dst = reinterpret_cast<float4*>(a.out + (size_t)(tp - (uint32_t)lane) * 14);
+    float4* dst = reinterpret_cast<float4*>(out_f + (size_t)(tp - (uint32_t)lane) * 14);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int q = lane + 64 * k;
       if (q < 224) dst[q] = src[q];
     }
   } else if (active) {
-    float* o = a.out + (size_t)tp * 14;
+    float* o = out_f + (size_t)tp * 14;
 #pragma unroll
     for (int c = 0; c < 14; c++) o[c] = px[c];
   }
+  }
+  if constexpr (FRAME_LOOP) {
+    __builtin_amdgcn_wave_barrier();  // (the wave's transpose slice is reused by its next frame)
+    if (++fr < fr_count) goto frame_top;
   }
 
   if constexpr (RNG == PT_RNG_XORWOW) {
@@ -507,6 +580,7 @@ __global__ void __launch_bounds__(kBlockThreads<VAR>, (kMinWavesR<VAR, REFB, RNG
     if (n_chunks > 1u) chunk_publish(a, block_id, chunk);  // count == chunks: this block's frame and generator state are complete
   }
 }
+
 
 // ---- variant 8: four lanes per pixel (small tiles) ----------------------------------------------
 // A rank of an 8-GPU run renders 131 072 pixels = 2 waves per SIMD with one lane per pixel, which is
@@ -1051,6 +1125,31 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
     grid *= a.chunks;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds, stream, b);
+  return hipGetLastError();
+}
+
+bool pt_kernel_has_frames(int variant, int n_spheres, int max_bounces, bool planar) {
+  return variant == 6 && ref_config(n_spheres, max_bounces, variant, planar) != 0;
+}
+
+// XORWOW: one workgroup per pixel block, looping over the batch's frames; philox: one per (frame, pixel block) (pixel_kernel, FRAMES)
+hipError_t pt_launch_frames_kernel(const FramesKernelArgs& fa, int rng_mode, hipStream_t stream) {
+  const PixelKernelArgs& a = fa.base;
+  const int ref = ref_config(a.n_spheres, a.max_bounces, 6, a.planar != 0u);
+  if (ref == 0 || fa.frames < 2u || fa.frames > (uint32_t)PT_FRAMES_MAX) return hipErrorInvalidValue;
+  const bool philox = rng_mode == PT_RNG_PHILOX;
+  typedef void (*frames_fn)(FramesKernelArgs);
+  frames_fn fn = ref == 5 ? (philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 5, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 5, true>)
+                          : (philox ? pt::pixel_kernel<PT_RNG_PHILOX, 6, false, 8, true> : pt::pixel_kernel<PT_RNG_XORWOW, 6, false, 8, true>);
+  FramesKernelArgs b = fa;
+  b.base.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, 6);
+  b.base.prio = (a.spp >= PT_PRIO_MIN_SPP || a.prio != 0u) ? 1u : 0u;
+  b.base.chunks = 0u;
+  b.base.repair = 0u;
+  const size_t lds = scene_lds_bytes(a.n_spheres, 6);
+  const unsigned block = (unsigned)PT_BLOCK_THREADS;
+  const unsigned blocks = (unsigned)(((uint64_t)a.tile_pixels + block - 1) / block);
+  hipLaunchKernelGGL(fn, dim3(philox ? blocks * fa.frames : blocks), dim3(block), lds, stream, b);
   return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 enum {
   PT_OK = 0,
@@ -158,6 +158,21 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
  * separate renderers. */
 int pt_renderer_enqueue(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
                         const float basis[12], const float eye[3], void* hip_stream);
+
+/* n_frames frames with KNOWN cameras: what n_frames calls of pt_renderer_enqueue(r, d_out + f * out_stride_floats, ..., bases +
+ * 12 f, eyes + 3 f, stream) do -- the body of the reference's frame loop (src/main.cu:146-177, `renderer.Render(...)` per
+ * iteration) for a scripted fly-through or a pose sweep (collect_data.py) -- same frames, same persisted generator state
+ * afterwards (src/pathtrace.cu:212,256), bit for bit.  For the reference's scene in the reference configuration (9 spheres, 5 or
+ * 8 bounces, interleaved layout: the interactive shape, whose single frame is one round of waves -- all ramp and tail) the frames
+ * go out as ONE launch per 32: a workgroup keeps its pixels for the whole batch and loops over the frames, the generator staying
+ * in its registers from frame to frame (the counter-based one is re-keyed per frame) -- no state traffic, one ramp and one tail
+ * per batch.  Elsewhere it IS the loop of single enqueues.
+ * d_vertices != NULL: frame f also writes its display vertices to d_vertices + f * vtx_stride_floats (pt_renderer_set_display
+ * for the batch).  Frames that would share a buffer (out_stride_floats below one tile, a set_display buffer without
+ * d_vertices) are rendered one by one.  bases / eyes are host arrays, read before the call returns. */
+int pt_renderer_enqueue_frames(pt_renderer* r, int n_frames, float* d_out, size_t out_stride_floats, float* d_vertices,
+                               size_t vtx_stride_floats, const pt_sphere* d_spheres, int n_spheres, const float* bases,
+                               const float* eyes, void* hip_stream);
 
 /* Status of the frames enqueued so far (wait != 0: block until the last one's status word has arrived): PT_OK, or
  * PT_EKERNEL once for a frame whose sample-chunk chain broke (see PT_EKERNEL; the next pt_renderer_enqueue /

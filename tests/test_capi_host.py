@@ -42,7 +42,7 @@ def test_product_library_is_lean_and_the_lab_library_is_a_superset(pt, lab):
 
 
 def test_abi_version_and_struct_layout(pt):
-    assert pt.lib.pt_abi_version() == 5
+    assert pt.lib.pt_abi_version() == 6
     assert pt.SPHERE_DTYPE.itemsize == 40          # include/Scene.h:7-14
     assert ctypes.sizeof(pt.RendererOpts) == 48 and ctypes.sizeof(pt.MgpuOpts) == 16
     o = pt.RendererOpts()

@@ -1,0 +1,107 @@
+"""pt_renderer_enqueue_frames: a batch of frames with known cameras in ONE launch (the reference's frame loop, src/main.cu:146-177,
+for a scripted fly-through).  Contract: exactly the frames -- and the persisted XORWOW state afterwards (src/pathtrace.cu:212,256)
+-- that the same sequence of single Render() calls produces; every frame against the frame-by-frame CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from test_parity_gpu import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def poses(pt, n, size):
+    """A short fly-through: the default camera drifting and turning a little every frame."""
+    bases, eyes = [], []
+    for k in range(n):
+        eye = (50.0 + 0.7 * k, 52.0 - 0.3 * k, 295.6 - 1.1 * k)
+        bases.append(pt.camera_basis(eye, yaw=-90.0 + 0.9 * k, pitch=-0.4 * k, width=size[0], height=size[1]))
+        eyes.append(eye)
+    return np.asarray(bases, dtype=np.float32), np.asarray(eyes, dtype=np.float32)
+
+
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+@pytest.mark.parametrize("mb", [8, 5])
+def test_frame_batch_equals_frame_by_frame_oracle(pt, oracle, gpu, rng, mb):
+    """The interactive shape (config 5's kernel, smaller image): 35 frames = two launches (32 + 3), display vertices fused."""
+    w, h, spp, n = 256, 128, 4, 35
+    scene = pt.scene_cornell()
+    bases, eyes = poses(pt, n, (w, h))
+    r = pt.Renderer(w, h, spp, max_bounces=mb, rng_mode=rng)
+    d_scene, ns = pt.upload_scene(scene)
+    d_out = pt.DeviceBuffer(n * w * h * 56)
+    d_vtx = pt.DeviceBuffer(n * w * h * 12)
+    r.enqueue_frames(d_out.ptr, w * h * 14, d_scene.ptr, ns, bases, eyes, d_vertices=d_vtx.ptr, vtx_stride_floats=w * h * 3)
+    assert r.check(wait=True) == 0
+    got = d_out.download(np.float32, (n, h, w, 14))
+    vtx = d_vtx.download(np.float32, (n, h, w, 3))
+    st = oracle.setup_random(w, h) if rng == 0 else None
+    for f in range(n):
+        ref = oracle.render(w, h, spp, spheres=scene, basis=bases[f], eye=eyes[f], max_bounces=mb, rng_mode=rng, rng_state=st, frame=f)
+        assert_bit_exact(got[f], ref, f"batched frame {f} rng {rng} bounces {mb}")
+        assert np.array_equal(vtx[f].view(np.uint32), oracle.display_pack(ref).view(np.uint32)), f"display vertices of frame {f}"
+    if rng == 0:
+        assert np.array_equal(r.get_rng_state(), st)
+    # the renderer goes on from there with single frames (frame counter and generator state are where 35 Render() calls leave them)
+    one = pt.DeviceBuffer(w * h * 56)
+    r.render(one.ptr, d_scene.ptr, ns, bases[0], eyes[0])
+    ref = oracle.render(w, h, spp, spheres=scene, basis=bases[0], eye=eyes[0], max_bounces=mb, rng_mode=rng, rng_state=st, frame=n)
+    assert_bit_exact(one.download(np.float32, (h, w, 14)), ref, "single frame after the batch")
+    r.destroy()
+
+
+def test_frame_batch_on_a_ragged_row_tile(pt, oracle, gpu):
+    """A rank's tile (rows 37..101 of a 200-wide image: waves straddle rows, the last workgroup is partly empty), xorwow."""
+    w, h, spp, n, rb, re_ = 200, 120, 4, 6, 37, 101
+    scene = pt.scene_cornell()
+    bases, eyes = poses(pt, n, (w, h))
+    r = pt.Renderer(w, h, spp, max_bounces=8, row_begin=rb, row_end=re_)
+    d_scene, ns = pt.upload_scene(scene)
+    tile = (re_ - rb) * w
+    d_out = pt.DeviceBuffer(n * tile * 56)
+    r.enqueue_frames(d_out.ptr, tile * 14, d_scene.ptr, ns, bases, eyes)
+    assert r.check(wait=True) == 0
+    got = d_out.download(np.float32, (n, re_ - rb, w, 14))
+    st = oracle.setup_random(w, h, row_begin=rb, row_end=re_)
+    for f in range(n):
+        ref = oracle.render(w, h, spp, spheres=scene, basis=bases[f], eye=eyes[f], max_bounces=8, row_begin=rb, row_end=re_, rng_state=st)
+        assert_bit_exact(got[f], ref, f"tile frame {f}")
+    assert np.array_equal(r.get_rng_state(), st)
+    r.destroy()
+
+
+def test_frame_batch_falls_back_to_single_frames_elsewhere(pt, oracle, gpu):
+    """No frames kernel for other scenes / kernels, and frames that share a buffer cannot be in flight together: the call is then the
+    loop of single enqueues it stands for -- same results."""
+    w, h, spp, n = 96, 64, 3, 4
+    bases, eyes = poses(pt, n, (w, h))
+    rs = np.random.default_rng(3)
+    scene = pt.scene_random(40, seed=9, with_walls=True)  # variant 10's territory
+    r = pt.Renderer(w, h, spp)
+    d_scene, ns = pt.upload_scene(scene)
+    d_out = pt.DeviceBuffer(n * w * h * 56)
+    r.enqueue_frames(d_out.ptr, w * h * 14, d_scene.ptr, ns, bases, eyes)
+    assert r.check(wait=True) == 0
+    got = d_out.download(np.float32, (n, h, w, 14))
+    st = oracle.setup_random(w, h)
+    for f in range(n):
+        ref = oracle.render(w, h, spp, spheres=scene, basis=bases[f], eye=eyes[f], rng_state=st)
+        assert_bit_exact(got[f], ref, f"40-sphere scene frame {f}")
+    r.destroy()
+    # the reference's scene, every frame into the SAME buffer (stride 0): rendered one by one, the last frame stays
+    scene = pt.scene_cornell()
+    r = pt.Renderer(w, h, spp, max_bounces=8)
+    d_scene, ns = pt.upload_scene(scene)
+    r.enqueue_frames(d_out.ptr, 0, d_scene.ptr, ns, bases, eyes)
+    assert r.check(wait=True) == 0
+    st = oracle.setup_random(w, h)
+    for f in range(n):
+        ref = oracle.render(w, h, spp, spheres=scene, basis=bases[f], eye=eyes[f], max_bounces=8, rng_state=st)
+    assert_bit_exact(d_out.download(np.float32, (n, h, w, 14))[0], ref, "stride 0: the last frame")
+    assert np.array_equal(r.get_rng_state(), st)
+    r.destroy()
+    with pytest.raises(pt.PtError):
+        r2 = pt.Renderer(w, h, spp)
+        try:
+            pt.check(pt.lib.pt_renderer_enqueue_frames(r2.handle, 2, d_out.ptr, w * h * 14, None, 0, d_scene.ptr, ns, None, None, None))
+        finally:
+            r2.destroy()
