@@ -2,6 +2,9 @@
 // everything behind them is libptcore.so.
 #ifndef RENDERER_H
 #define RENDERER_H
+#include <chrono>
+#include <vector>
+
 #include "Camera.h"
 #include "HipErrorCheck.h"
 #include "pathtrace.h"
@@ -47,6 +50,33 @@ class Renderer {
     gpuErrchk(pt_renderer_render(impl, d_buffer.buffer, reinterpret_cast<const pt_sphere*>(d_scene.objects),
                                  d_scene.numObjects, basis, eye, &milliseconds));
     return milliseconds;
+  }
+
+  // Extension (no reference counterpart: main.cu:146-148 calls Render once per loop iteration): the frames of a scripted
+  // fly-through in one call -- frame k with cameras[k] into d_frames + k * width * height * 14, generator state carried from
+  // frame to frame exactly as by Render (pt_renderer_enqueue_frames).  Synchronous; returns wall milliseconds for all frames.
+  float RenderFrames(float* d_frames, const Scene& d_scene, const std::vector<Camera>& cameras) {
+    std::vector<float> bases(12 * cameras.size()), eyes(3 * cameras.size());
+    for (size_t f = 0; f < cameras.size(); f++) {
+      float3 eyeRayBasis[4];
+      cameras[f].getEyeRayBasis(eyeRayBasis, width, height);
+      for (int k = 0; k < 4; k++) {
+        bases[12 * f + 3 * k] = eyeRayBasis[k].x;
+        bases[12 * f + 3 * k + 1] = eyeRayBasis[k].y;
+        bases[12 * f + 3 * k + 2] = eyeRayBasis[k].z;
+      }
+      eyes[3 * f] = cameras[f].Position.x;
+      eyes[3 * f + 1] = cameras[f].Position.y;
+      eyes[3 * f + 2] = cameras[f].Position.z;
+    }
+    gpuErrchk(pt_device_synchronize());
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    gpuErrchk(pt_renderer_enqueue_frames(impl, (int)cameras.size(), d_frames, (size_t)width * height * 14, NULL, 0,
+                                         reinterpret_cast<const pt_sphere*>(d_scene.objects), d_scene.numObjects, bases.data(),
+                                         eyes.data(), NULL));
+    gpuErrchk(pt_device_synchronize());
+    gpuErrchk(pt_renderer_check(impl, 1, NULL));
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 };
 #endif

@@ -48,6 +48,7 @@ static void usage() {
                "  --spheres arg                 render a seeded random scene of N spheres\n"
                "  --frames arg                  render N frames back to back (headless interactive loop)\n"
                "  --poses arg                   fly-through: file with one 'x y z yaw pitch' line per frame\n"
+               "  --batch                       with --poses: render the fly-through in batches of 32 frames per launch\n"
                "  --gpus arg                    row-tile the frame over N devices starting at --device (RCCL gather)\n"
                "  --preview arg                 also write the display-packed frame (Denoiser) as a binary PPM\n"
             << std::endl;
@@ -66,6 +67,8 @@ int main(int argc, const char** argv) {
   std::string rng = "xorwow";
   int maxBounces = 5, nSpheres = 0, frames = 1, gpus = 1;
   std::string posesFile, previewFile;
+  bool batch = false;        // --poses: all frames in one call (one launch per 32 frames)
+  void* batch_frames = NULL;
 
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -97,6 +100,7 @@ int main(int argc, const char** argv) {
     else if (a == "--frames") frames = atoi(value("--frames"));
     else if (a == "--gpus") gpus = atoi(value("--gpus"));
     else if (a == "--poses") posesFile = value("--poses");
+    else if (a == "--batch") batch = true;
     else if (a == "--preview") previewFile = value("--preview");
     else {
       std::cerr << "ERROR: unrecognised option '" << a << "'" << std::endl << std::endl;
@@ -169,18 +173,37 @@ int main(int argc, const char** argv) {
       return 1;
     }
     std::vector<float> times;
+    std::vector<Camera> cameras;
     std::string line;
     while (std::getline(in, line)) {
       std::istringstream ls(line);
       float x, y, z, yaw, pitch;
       if (!(ls >> x >> y >> z >> yaw >> pitch)) continue;
-      Camera pose(glm::vec3(x, y, z), yaw, pitch);
-      renderTime = render(d_buffer, scene, pose);
-      times.push_back(renderTime);
+      cameras.push_back(Camera(glm::vec3(x, y, z), yaw, pitch));
     }
-    if (times.empty()) {
+    if (cameras.empty()) {
       std::cerr << "ERROR: no poses in " << posesFile << std::endl;
       return 1;
+    }
+    if (batch && single) {
+      // every pose is known before the first frame: one call, one launch per 32 frames (Renderer::RenderFrames); each frame
+      // has its own buffer, the last one is what gets saved
+      void* d_frames = NULL;
+      const size_t frame_floats = (size_t)width * height * 14;
+      gpuErrchk(pt_malloc(&d_frames, cameras.size() * frame_floats * sizeof(float)));
+      const float ms = single->RenderFrames(static_cast<float*>(d_frames), scene, cameras);
+      std::cout << "Fly-through in batches: " << cameras.size() << " frames, " << ms / cameras.size() << "ms per frame ("
+                << 1000.0 * cameras.size() / ms << " fps)" << std::endl;
+      d_buffer.FreeGPU();
+      batch_frames = d_frames;
+      d_buffer.buffer = static_cast<float*>(d_frames) + (cameras.size() - 1) * frame_floats;
+      renderTime = ms / cameras.size();
+      times.push_back(renderTime);
+    } else {
+      for (size_t f = 0; f < cameras.size(); f++) {
+        renderTime = render(d_buffer, scene, cameras[f]);
+        times.push_back(renderTime);
+      }
     }
     std::vector<float> sorted(times);
     std::sort(sorted.begin(), sorted.end());
@@ -231,7 +254,8 @@ int main(int argc, const char** argv) {
   buffer.FreeCPU();
   delete single;
   delete tiled;
-  d_buffer.FreeGPU();
+  if (batch_frames) (void)pt_free(batch_frames);  // (d_buffer points into it)
+  else d_buffer.FreeGPU();
   scene.Free();
   return 0;
 }

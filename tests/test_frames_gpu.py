@@ -105,3 +105,27 @@ def test_frame_batch_falls_back_to_single_frames_elsewhere(pt, oracle, gpu):
             pt.check(pt.lib.pt_renderer_enqueue_frames(r2.handle, 2, d_out.ptr, w * h * 14, None, 0, d_scene.ptr, ns, None, None, None))
         finally:
             r2.destroy()
+
+
+def test_cli_fly_through_in_batches_writes_the_same_file(pt, gpu, tmp_path):
+    """pathtrace --poses FILE --batch (Renderer::RenderFrames): the saved last frame is byte for byte the file the frame-by-frame
+    fly-through writes (which tests/test_parity_gpu.py holds against the oracle)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    rs = np.random.default_rng(2)
+    pf = tmp_path / "poses.txt"
+    pf.write_text("".join("%g %g %g %g %g\n" % (50 + rs.uniform(-5, 5), 52 + rs.uniform(-5, 5), 295.6 - 3 * k, -90 + rs.uniform(-4, 4), rs.uniform(-3, 3))
+                          for k in range(37)))
+    exe = os.path.join(ROOT, "cuda-pathtrace_amd", "pathtrace")
+    files = []
+    for extra, tag in (([], "loop"), (["--batch"], "batch")):
+        out = str(tmp_path / tag)
+        res = subprocess.run([exe, "--size", "96", "-s", "4", "--max-bounces", "8", "--poses", str(pf), "--nobitmap", "-o", out] + extra,
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert ("Fly-through in batches: 37 frames" in res.stdout) == bool(extra)
+        files.append(open(out + ".exr", "rb").read())
+    assert files[0] == files[1] and len(files[0]) > 96 * 96 * 56
