@@ -1197,6 +1197,10 @@ __device__ __forceinline__ void grid_trips_pooled(GridWalk& walk, const GridLds&
 #pragma unroll
     for (int k = 0; k < K; k++) push(e0[k], e1[k], self, k == 0);
     const bool fin = __builtin_amdgcn_ballot_w64(walking | (links != 0u)) == 0;
+    // (Measured and dropped, round 5: requesting the next cells BEFORE the drain, so that their LDS round trip overlaps the drain's --
+    // the steps then see a stop parameter one drain older, walk further and test more: closed / open 71.0 / 22.5 -> 76.5 / 24.3 ms.
+    // Issuing the best estimate's read-back ahead of the remainder's read, to overlap the two round trips: no difference.
+    // profiles/r05/cfg4_ab.txt)
     drain(fin);
     if (fin) break;
     if (__builtin_expect(--rounds_left < 0, 0)) {  // (wave-uniform)
