@@ -79,7 +79,7 @@ class KernelInfo(ctypes.Structure):
         ("grid_blocks", ctypes.c_int32),
         ("lds_bytes", ctypes.c_int32),
         ("num_vgprs", ctypes.c_int32),
-        ("num_sgprs", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
         ("scratch_bytes", ctypes.c_int32),
         ("max_spheres", ctypes.c_int32),
         ("variant", ctypes.c_int32),
@@ -141,6 +141,7 @@ LAB_ABI = {
                                             ctypes.POINTER(ctypes.c_uint32)]),
     "pt_debug_grid_header": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
     "pt_debug_policy_ms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "pt_debug_policy_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
 }
 
 FN_INV_SQRT_LITERAL, FN_INV_SQRT_FAST, FN_SQRT_LITERAL, FN_SQRT_FAST, FN_SIN, FN_COS, FN_UNIFORM = range(7)
@@ -321,13 +322,11 @@ def policy_ms(rng_mode, variant, waves_per_simd, spp, bounces=5):
 
 
 def policy_choice(rng_mode, waves_per_simd, spp, bounces=5, with9=True):
-    """... and the variant it therefore picks for the reference's scene (variant 6 keeps a tie)."""
-    best, best_ms = 6, None
-    for v in (6, 8, 9) if with9 else (6, 8):
-        ms = policy_ms(rng_mode, v, waves_per_simd, spp, bounces)
-        if best_ms is None or ms < best_ms:
-            best, best_ms = v, ms
-    return best
+    """... and the variant the library's OWN policy code (cheapest_variant, csrc/pt_capi.hip) picks from it for the reference's
+    scene, in the regime a default renderer is in (samples chunked from 512 spp on): pt_debug_policy_choice."""
+    v = ctypes.c_int(0)
+    check(lib.pt_debug_policy_choice(rng_mode, waves_per_simd, spp, bounces, 1 if with9 else 0, 1 if spp >= 512 else 0, ctypes.byref(v)))
+    return v.value
 
 
 def grid_header(spheres):
@@ -425,7 +424,7 @@ class Renderer:
     def kernel_info(self, n_spheres):
         ki = KernelInfo()
         check(lib.pt_renderer_kernel_info(self.handle, n_spheres, ctypes.byref(ki)))
-        return {f: getattr(ki, f) for f, _ in KernelInfo._fields_}
+        return {f: getattr(ki, f) for f, _ in KernelInfo._fields_ if not f.startswith("reserved")}
 
     def destroy(self):
         if self.handle:

@@ -124,13 +124,14 @@ static double predicted_ms(const KernelCost& c, double w, int spp, int bounces, 
 }
 
 // the cheapest of variants 6, 8 (and 9 where it has a build: the reference configuration) for this tile
-static int cheapest_variant(int rng_mode, double w, int spp, int bounces, bool with9) {
-  const bool chunked = spp >= 512;  // (every one of the three chunks its samples from there on, pt_renderer_create)
+// chunked_mask: bit v set = a launch of variant v would chunk its samples (the regime is a property of the renderer --
+// opts.chunks, PT_CHUNKS, a failed hand-over allocation, a broken chain all switch chunking off -- not of spp alone)
+static int cheapest_variant(int rng_mode, double w, int spp, int bounces, bool with9, uint32_t chunked_mask) {
   int best = PT_DEFAULT_VARIANT;
   double best_ms = 1e300;
   for (const KernelCost& c : kKernelCost[rng_mode == PT_RNG_PHILOX ? 1 : 0]) {
     if (c.variant == 9 && !with9) continue;
-    const double ms = predicted_ms(c, w, spp, bounces, chunked);
+    const double ms = predicted_ms(c, w, spp, bounces, ((chunked_mask >> c.variant) & 1u) != 0u);
     if (ms < best_ms) best = c.variant, best_ms = ms;  // (variant 6 comes first: it keeps a tie)
   }
   return best;
@@ -152,8 +153,14 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   if (n_spheres > PT_SCREEN_MAX_SPHERES) return (xorwow && r->small_tile && r->spec_ok && r->spp >= 8) ? 8 : 10;
   // splitting a pixel's samples over lanes needs samples to split, and (xorwow) a speculation that holds
   if (r->spp < 4 || (xorwow && !r->spec_ok)) return PT_DEFAULT_VARIANT;
-  const bool ref = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, r->opts.layout == PT_LAYOUT_PLANAR) != 0;
-  return cheapest_variant(r->opts.rng_mode, r->waves_per_simd, r->spp, r->opts.max_bounces > 0 ? r->opts.max_bounces : 1, ref);
+  const bool planar = r->opts.layout == PT_LAYOUT_PLANAR;
+  const bool ref = pt_kernel_ref_bounces(n_spheres, r->opts.max_bounces, 9, planar) != 0;
+  uint32_t chunked_mask = 0u;
+  for (int v : {6, 8, 9}) {
+    const uint32_t c = v == 6 ? r->chunks : r->chunks_split;
+    if (c >= 2u && pt_kernel_chunked(v, n_spheres, r->opts.max_bounces, planar, r->spp, c)) chunked_mask |= 1u << v;
+  }
+  return cheapest_variant(r->opts.rng_mode, r->waves_per_simd, r->spp, r->opts.max_bounces > 0 ? r->opts.max_bounces : 1, ref, chunked_mask);
 }
 
 // opts.chunks, or env PT_CHUNKS when that is 0: 0 = automatic, 1 = never, 2..PT_CHUNKS_MAX = that many (anything else: automatic)
@@ -690,6 +697,10 @@ int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres,
     PT_HIP(hipEventElapsedTime(&ms2, r->ev_start, r->ev_stop));
     ms += ms2;
     r->repaired++;
+    // not an error (the frame is complete), but never silent either: the caller's frame time holds the whole wait
+    snprintf(g_err, sizeof(g_err), "render: sample-chunk chain broken (device error word 0x%x) -- frame repaired in place by a second, unchunked "
+             "launch over the untouched pixel blocks; the returned time includes the %ld ms wait; chunking is now off for this renderer", err, r->chunk_wait_ms);
+    fprintf(stderr, "ptcore: %s\n", g_err);
   }
   if (ms_out) *ms_out = ms;
   return PT_OK;
@@ -702,6 +713,13 @@ int pt_renderer_check(pt_renderer* r, int wait, uint32_t* repaired_frames) {
 }
 
 #if PT_BUILD_EXPERIMENTS
+// lab library: the variant the C++ policy itself picks for a tile of the reference's scene (tests/test_policy_model.py compares
+// it with the Python restatement of the argmin)
+int pt_debug_policy_choice(int rng_mode, double waves_per_simd, int spp, int bounces, int with9, int chunked, int* variant) {
+  if (!variant) return pt_fail(PT_EINVAL, "pt_debug_policy_choice: variant is NULL");
+  *variant = cheapest_variant(rng_mode, waves_per_simd, spp, bounces, with9 != 0, chunked ? ((1u << 6) | (1u << 8) | (1u << 9)) : 0u);
+  return PT_OK;
+}
 // lab library: the policy's cost model, for tests/test_policy_model.py (include/ptcore_lab.h)
 int pt_debug_policy_ms(int rng_mode, int variant, double waves_per_simd, int spp, int bounces, double* ms) {
   if (!ms) return pt_fail(PT_EINVAL, "pt_debug_policy_ms: ms is NULL");
@@ -767,7 +785,7 @@ int pt_renderer_kernel_info(pt_renderer* r, int n_spheres, pt_kernel_info* info)
       pt_kernel_chunked(variant, n_spheres, r->opts.max_bounces, r->opts.layout == PT_LAYOUT_PLANAR, r->spp, chunks_of(r, variant)))
     info->grid_blocks *= (int)chunks_of(r, variant);  // sample chunking: that many workgroups per pixel block
   info->num_vgprs = fa.numRegs;
-  info->num_sgprs = 0;
+  info->reserved0 = 0;
   info->scratch_bytes = (int)fa.localSizeBytes;
   info->max_spheres = fast ? (1 << 26) : pt_kernel_max_spheres(variant);
   return PT_OK;

@@ -26,7 +26,7 @@ constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POO
 // WRITE_SIZE stays at the algorithmic bytes): five waves per SIMD instead of four (headline frame 50.12 -> 49.81 ms, three
 // alternating runs each, profiles/r03/README.md).  The philox builds spilled warm then (WRITE_SIZE 143 -> 400 MB per frame) and
 // gained nothing; after the bit-operation work of round 3 the 5-bounce build fits 96 registers with ONE spilled word (a reload
-// per sample) and gains 1.5 % (48.73 -> 47.98 ms, tools/philox_ab.py); the 8-bounce build (4 words) does not (0.0963 -> 0.0971 ms)
+// per sample) and gains 1.5 % (48.73 -> 47.98 ms, profiles/r03/README.md); the 8-bounce build (4 words) does not (0.0963 -> 0.0971 ms)
 // and keeps four waves, like every other build.
 template <int VAR, int REFB, int RNG>
 constexpr int kMinWavesR = (VAR == 6 && REFB != 0) ? (RNG == PT_RNG_XORWOW ? PT_REF_MIN_WAVES : (REFB == 5 ? PT_REF_MIN_WAVES_PHILOX : kMinWaves<VAR>)) : kMinWaves<VAR>;

@@ -99,7 +99,7 @@ __device__ __forceinline__ bool build_primary_list(const GridLds& G, const pt_sp
     dev = !(len <= dev) ? len : dev;  // (a NaN stays)
   }
   const float rho = kPrimRadiusFactor * dev / lc + 1e-6f;
-  bool ok = active & (rho <= 0.00390625f) & (lc > 0.0f) & (dev >= 0.0f);  // NaN, degenerate or coarse footprint: no list
+  bool ok = active & (rho <= 0.125f) & (lc > 0.0f) & (dev >= 0.0f);  // NaN or degenerate footprint: no list (1.05 x >= asin x up to 0.3)
   const F3 u = dc * (1.0f / lc);
   // one cone around all the wave's footprints: axis between the first and the last pixel's directions
   const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);

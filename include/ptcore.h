@@ -144,7 +144,9 @@ int pt_renderer_destroy(pt_renderer* r);
  * renderer: the buffer base).  basis = the 4 corner directions of
  * Camera::getEyeRayBasis (Camera.h:125-149), eye = camera.Position.  Synchronous like the
  * reference (returns after the stop event), *ms_out = kernel-only milliseconds from a
- * hipEvent pair (Renderer.h:63-75).  ms_out may be NULL. */
+ * hipEvent pair (Renderer.h:63-75).  ms_out may be NULL.  (A frame whose sample-chunk chain broke -- never observed; see
+ * PT_EKERNEL -- is repaired in place by a second launch: *ms_out then holds both launches INCLUDING the wait limit, default
+ * 4 s, a line goes to stderr, pt_last_error() carries the same text and pt_renderer_check counts the frame.) */
 int pt_renderer_render(pt_renderer* r, float* d_out, const pt_sphere* d_spheres, int n_spheres,
                        const float basis[12], const float eye[3], float* ms_out);
 
@@ -201,7 +203,7 @@ typedef struct pt_kernel_info {
   int32_t grid_blocks;
   int32_t lds_bytes;
   int32_t num_vgprs;    /* from hipFuncGetAttributes */
-  int32_t num_sgprs;
+  int32_t reserved0;    /* always 0 (was num_sgprs up to ABI 5: hipFuncGetAttributes does not report scalar registers) */
   int32_t scratch_bytes;
   int32_t max_spheres;  /* LDS staging limit for this variant (2^26 where larger scenes are not staged) */
   int32_t variant;      /* the variant the next launch will use (resolves the automatic choice) */

@@ -51,6 +51,8 @@ int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t hea
  * variant 6, 8 or 9 on a tile of `waves_per_simd` one-lane waves per SIMD at `spp` samples and `bounces` bounces.  Host
  * arithmetic only (no device needed): tests/test_policy_model.py holds it against the measured sweeps under profiles/. */
 int pt_debug_policy_ms(int rng_mode, int variant, double waves_per_simd, int spp, int bounces, double* ms);
+/* the variant the library's own cost-model policy picks (6, 8 or 9) for a tile of `waves_per_simd` one-lane waves per SIMD */
+int pt_debug_policy_choice(int rng_mode, double waves_per_simd, int spp, int bounces, int with9, int chunked, int* variant);
 
 #ifdef __cplusplus
 }

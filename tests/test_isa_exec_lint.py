@@ -66,3 +66,50 @@ def test_built_libraries_are_clean():
         assert lint_mod.lint(f) == [], f
         kernels += sum(1 for line in open(f) if line.startswith("_Z") and "pixel_kernel" in line and line.split(";")[0].rstrip().endswith(":"))
     assert kernels > 20  # (the assembly really is the kernels': both libraries' pixel_kernel instantiations)
+
+
+def test_pooled_push_is_three_separate_descending_stores():
+    """The push of variant 13's pooled walk (csrc/pt_grid.h, grid_trips_pooled (1)) relies on its three ring
+    stores going out as three separate ds_write_b32 in DESCENDING slot order: a lane with fewer than three spheres writes garbage
+    into slots a later store of the same push overwrites -- a ds_write2_b32 / ds_write_b64 fusing two of them would let a lane's
+    garbage race its neighbour's rightful value inside one instruction (nothing pinned this).  Read from the assembly
+    of the installed builds: every block that computes ring positions (six chained v_mbcnt) and stores must show exactly that."""
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "cuda-pathtrace_amd", "csrc", "build", "*", "pt_kernel-*-gfx950.s")))
+    if not files:
+        pytest.skip("no build directory here (the libraries were built elsewhere)")
+    pushes = 0
+    for f in files:
+        kernel, block = None, []
+
+        def check(block):
+            n = 0
+            mb = sum(1 for i in block if i.startswith("v_mbcnt"))
+            st = [i for i in block if i.startswith("ds_write")]
+            if mb >= 6 and st:
+                assert all(i.split()[0] == "ds_write_b32" for i in st), (f, kernel, st)
+                assert len(st) == 3, (f, kernel, st)
+                regs = {i.split()[1].rstrip(",") for i in st}
+                offs = [int(re.search(r"offset:(\d+)", i).group(1)) if "offset:" in i else 0 for i in st]
+                assert len(regs) == 1 and offs[0] == offs[1] + 4 == offs[2] + 8, (f, kernel, st)
+                n = 1
+            return n
+
+        for line in open(f):
+            s = line.strip()
+            m = re.match(r"(_Z\w+):", s)
+            if m:
+                kernel, block = (m.group(1) if "Li13E" in m.group(1) else None), []
+                continue
+            if kernel is None:
+                continue
+            if s.startswith(".Lfunc_end"):
+                pushes += check(block)
+                kernel = None
+            elif re.match(r"\.LBB\d+_\d+:", s):
+                pushes += check(block)
+                block = []
+            elif s and not s.startswith((";", ".")):
+                block.append(s.split(";")[0].strip())
+    assert pushes >= 2 * 2 * 3  # two libraries x two generators x (two pushes of a lock-step round + the sweep's)

@@ -57,3 +57,9 @@ def test_model_shape(lab):
     assert lab.policy_ms(0, 6, 5.06, 64) > 1.3 * lab.policy_ms(0, 6, 5.0, 64)  # a sixth wave per SIMD starts a second round
     assert lab.policy_choice(0, 1.0, 1024) == 8 and lab.policy_choice(0, 16.0, 1024) == 6 and lab.policy_choice(0, 2.0, 1024) == 9
     assert lab.policy_choice(0, 2.0, 1024, with9=False) == 8
+    # the C++ choice is the argmin of the C++ model (pt_debug_policy_choice against pt_debug_policy_ms)
+    for rng in (0, 1):
+        for w in (0.5, 1.0, 2.0, 3.5, 8.0, 16.0):
+            for spp in (4, 64, 1024):
+                ms = {v: lab.policy_ms(rng, v, w, spp) for v in (6, 8, 9)}
+                assert ms[lab.policy_choice(rng, w, spp)] == min(ms.values()), (rng, w, spp, ms)

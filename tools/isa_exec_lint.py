@@ -3,7 +3,9 @@
 lanes which sat out the preceding divergent region.  The register allocator's live-range splitting of this compiler has been
 seen to put the copies of a split there: they then run for the lanes that took the region only -- for NO lane
 when the region was skipped -- and the value the other lanes carry is lost.  Usage: isa_exec_lint.py file.s...
-(the library's Makefile runs it over the assembly of every build; exit status 1 = found)"""
+(the library's Makefile runs it over the assembly of every build; exit status 1 = found, 2 = nothing to read;
+PT_SKIP_ISA_LINT=1 in the environment skips it.  A HEURISTIC: it knows the one shape seen so far -- a block head that holds nothing
+but register copies / spill traffic before the restore -- and the parity suite and soaks remain the gate for everything else.)"""
 import re, sys
 
 def lint(path, only=None):
@@ -29,7 +31,8 @@ def lint(path, only=None):
         if op == "s_or_b64" and re.match(r"s_or_b64\s+exec,\s*exec,", s):
             # copies and spill traffic only: computation there belongs to the region that is ending (an out-of-line block
             # that closes its own region), which is how the compiler normally lays such blocks out
-            copies = pending and all(re.match(r"(v_mov_b32_e32 v\d+, v\d+|v_mov_b64_e32 v\[[\d:]+\], v\[[\d:]+\]|v_accvgpr_\w+ |scratch_(load|store)_)", i) for i in pending)
+            # (any v_mov -- from a vector or scalar register or a constant: a rematerialised value is a split's copy too)
+            copies = pending and all(re.match(r"(v_mov_b32_e32 v\d+, |v_mov_b64_e32 v\[[\d:]+\], |v_accvgpr_\w+ |scratch_(load|store)_)", i) for i in pending)
             if copies and (only is None or (kernel and only in kernel)):
                 found.append((kernel, label, ln, pending[:]))
             pending = None
@@ -41,11 +44,21 @@ def lint(path, only=None):
     return found
 
 if __name__ == "__main__":
+    import glob, os
+    if os.environ.get("PT_SKIP_ISA_LINT") == "1":  # escape hatch: a heuristic on text must never make the library unbuildable
+        print("isa_exec_lint: skipped (PT_SKIP_ISA_LINT=1); the parity tests and soaks are the gate")
+        sys.exit(0)
+    paths = [p for a in sys.argv[1:] for p in (glob.glob(a) or [a])]
+    missing = [p for p in paths if not os.path.exists(p)]
+    if missing or not paths:
+        print(f"isa_exec_lint: no assembly to read ({missing or 'no arguments'}): was the library compiled with -save-temps for this "
+              f"--offload-arch?  Set PT_SKIP_ISA_LINT=1 to build without the lint.")
+        sys.exit(2)
     total = 0
-    for path in sys.argv[1:]:
+    for path in paths:
         res = lint(path)
         total += len(res)
         for k, lab, ln, ins in res:
             print(f"{path}: {k} {lab} (line {ln}): {len(ins)} copy/spill instruction(s) before the exec restore: {ins[:4]}")
-    print(f"isa_exec_lint: {len(sys.argv) - 1} file(s), {total} suspect block head(s)")
+    print(f"isa_exec_lint: {len(paths)} file(s), {total} suspect block head(s)")
     sys.exit(1 if total else 0)
