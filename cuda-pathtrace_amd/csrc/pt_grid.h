@@ -662,7 +662,7 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
       const int i = (int)G.big[k];
       const float4 gi = G.bigg[k];
       // (a wave-uniform branch around the doubted lanes' region: the join of a DIVERGENT one here is where this compiler's
-      // register allocator put the copies of a live-range split in front of the exec restore -- DESIGN.md A.12,
+      // register allocator put the copies of a live-range split in front of the exec restore -- EXACTNESS.md A.12,
       // tools/isa_exec_lint.py, which the build runs over every kernel)
       const bool doubt = near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi);
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(doubt) != 0ull, 0)) {
@@ -863,7 +863,7 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
 
 // `last` (variant 13's regeneration loop, round 5): the caller uses only the hit/miss decision and the index -- the last bounce of
 // a path: emission of the sphere hit, nothing else; t, the hit point and the next ray are dead.  The winner's FP64 exact step is
-// then replaced by its float part and the two certainty tests of intersect_scene_screened_keys' LAST (pt_intersect.h; DESIGN.md
+// then replaced by its float part and the two certainty tests of intersect_scene_screened_keys' LAST (pt_intersect.h; EXACTNESS.md
 // A.8 "Last bounce"), in this file's units: estimates are of 2a t and b = 2 d.off, so dacc here is four times dacc there and
 // a4 c four times a c -- exact powers of two on both sides of every compare.  A winner that fails either test goes the usual way.
 __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d,
@@ -956,7 +956,7 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 //    are the same sphere met in two cells and are entered once (what near2_test's leader check does);
 //  * the owner reads its best estimate back after a drain, for the stop rule of its next steps.  That value may be stale by
 //    the entries still in the ring: the rule then fires later, never earlier -- more cells, more tests, the same superset
-//    argument as the look-ahead step of variant 11 (exactness appendix A.6 (iii-b)).
+//    argument as the look-ahead step of variant 11 (EXACTNESS.md A.6 (iii-b)).
 // Round 4.  Counters (profiles/r04): the walk is ISSUE-bound, not latency-bound -- 71 vector instructions per round and cell
 // (24.6 rounds per wave-walk with 16.5 of 64 lanes stepping), most of them at the half rate (compares, selects), against 48 per
 // drain of 60 tests.  So the rounds were rebuilt for instruction count:
@@ -973,7 +973,7 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 //  * after a drain the ring's remainder (less than a pass) moves to the ring's start, so positions need no wrap-around;
 //  * the best estimate is read back only after a drain (nothing else can change it).
 // (The walk-range hand-over of round 3's lab build -- idle lanes taking the far half of a busy lane's walk -- is gone: a
-// measured negative result)
+// measured negative result, HISTORY.md B.5.)
 // Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
 // expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
 // (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
@@ -1406,7 +1406,7 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
   GridWalk w;
   // (no branch around grid_begin for the helpers: they run it on whatever ray they last had -- the wave executes it anyway -- and
   // their walk is then emptied with selects.  A divergent region that ends here, in front of the register-hungry walk, is where
-  // the allocator's split copies landed in front of the exec restore: DESIGN.md A.12.)
+  // the allocator's split copies landed in front of the exec restore: EXACTNESS.md A.12.)
   grid_begin<true>(w, G, o, d, a, prim & walker, walker);
   const float INF = __builtin_inff();
   w.s.T1 = walker ? w.s.T1 : INF;

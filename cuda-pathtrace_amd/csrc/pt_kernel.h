@@ -70,7 +70,7 @@
 // The grid kernel (variant 11) is latency-bound -- dependent LDS reads and a long dependency chain per sphere test -- so it
 // wants WAVES, and its 36 KB LDS image (geometry + tables at 1000 spheres) is per workgroup: 256-thread workgroups stop at
 // four per CU (4 waves per SIMD).  512-thread workgroups share one image between eight waves; with the register cap below
-// six waves per SIMD fit (three workgroups, 108 KB).  Measured at 1000 spheres, 32 spp: 256/4 27.0 ms, see DESIGN.md.
+// six waves per SIMD fit (three workgroups, 108 KB).  Measured at 1000 spheres, 32 spp: 256/4 27.0 ms, see HISTORY.md B.3.
 #define PT_GRID_BLOCK_THREADS 512
 #endif
 #ifndef PT_GRID_MIN_WAVES

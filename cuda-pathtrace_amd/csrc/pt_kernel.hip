@@ -158,7 +158,7 @@ pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch ha
 
   // Sample chunking (REF builds of variant 6, variant 13): workgroup blockIdx.x = chunk * n_blocks + block renders samples
   // [chunk * per, (chunk + 1) * per) of its 256 pixels and hands generator, sums and Welford accumulators to the next chunk
-  // through chunk_state.  Forward progress ("sample chunking"): every dispatcher hands out its workgroups in
+  // through chunk_state.  Forward progress (DESIGN.md section 3 ("sample chunking")): every dispatcher hands out its workgroups in
   // increasing index order, so by induction on the lowest unfinished index the predecessor of a waiting workgroup is resident
   // or done -- and the lowest unfinished one never waits.  That is a property of today's hardware, not of the programming
   // model, so the wait is bounded in time and giving up raises the renderer's error word (PT_EKERNEL), never a silent frame.
@@ -584,7 +584,7 @@ frame_top:
 
 // ---- variant 8: four lanes per pixel (small tiles) ----------------------------------------------
 // A rank of an 8-GPU run renders 131 072 pixels = 2 waves per SIMD with one lane per pixel, which is
-// latency-bound.  Here lane (pixel, s) traces samples s, s+4, s+8, ... so the same tile
+// latency-bound (HISTORY.md B.2).  Here lane (pixel, s) traces samples s, s+4, s+8, ... so the same tile
 // has 4x the waves.  What the contract fixes -- one sequential generator per pixel, sequential float
 // sums, sequential Welford updates -- is preserved:
 //  * xorwow: lane s starts from the pixel's state advanced by s*D draws and skips 3*D draws after each

@@ -12,7 +12,7 @@
 // Why no result can change: a sphere is left out of a pixel's list only if the REFERENCE ITSELF can never accept it for any
 // direction d of the footprint -- its own float discriminant is negative (pathtrace.cu:77-79), or both roots are (:82-88, :99).
 // What is left goes through the unchanged machinery, whose only requirement on the tested set is that it contains the sphere the
-// reference returns.  Everything below is an inequality with slack, evaluated in FP64 on the reference's own
+// reference returns (EXACTNESS.md A.6/A.9).  Everything below is an inequality with slack, evaluated in FP64 on the reference's own
 // float operands; NaN or unusual geometry makes a comparison false, and false always means "keep the sphere" / "no list".
 //
 // Notation: off = eye - centre and rr = r * r as the reference rounds them (float); o2 = |off|^2, a = |d|^2, in real arithmetic

@@ -1,7 +1,7 @@
 /*
  * ptcore_lab.h -- additional exports of libptcore_lab.so, the LAB build of the same sources
  * (csrc/Makefile, -DPT_BUILD_EXPERIMENTS=1): everything in ptcore.h, plus the experimental kernel
- * variants 1-5, 7, 11 and 12 (stepping stones, superseded kernels and measured negative results) and the
+ * variants 1-5, 7, 11 and 12 (stepping stones, superseded kernels and measured negative results, HISTORY.md B.2) and the
  * diagnostic entry points below.  Loaded by the variant / exhaustive tests and the tools; the
  * product library libptcore.so exports none of this.  No reference counterpart.
  */

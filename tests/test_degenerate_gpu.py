@@ -1,5 +1,5 @@
 """Degenerate scenes (NaN / infinite / huge / denormal sphere data, duplicated spheres, the eye exactly on a surface looking
-along a tangent): what the exactness arguments of DESIGN.md Appendix A say about NaN propagation, rejected candidates and
+along a tangent): what the exactness arguments of EXACTNESS.md say about NaN propagation, rejected candidates and
 doubted estimates, checked against the oracle bit for bit on every kernel family (tools/degenerate_soak.py)."""
 import json
 import os

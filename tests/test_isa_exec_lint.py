@@ -1,4 +1,4 @@
-"""tools/isa_exec_lint.py, the check the library's Makefile runs over the assembly of every build: vector copies
+"""tools/isa_exec_lint.py, the check the library's Makefile runs over the assembly of every build (EXACTNESS.md A.12): vector copies
 between the head of a basic block and the `s_or_b64 exec, exec, ...` that re-opens the lanes which sat out the region before it.
 The lint itself on the two shapes (the miscompiled join as it was found in variant 13's philox build, and a well-formed join),
 and over the assembly the last `make` left under cuda-pathtrace_amd/csrc/build/ -- the exact instruction stream of the
@@ -69,7 +69,7 @@ def test_built_libraries_are_clean():
 
 
 def test_pooled_push_is_three_separate_descending_stores():
-    """The push of variant 13's pooled walk (csrc/pt_grid.h, grid_trips_pooled (1)) relies on its three ring
+    """The push of variant 13's pooled walk (csrc/pt_grid.h, grid_trips_pooled (1); EXACTNESS.md A.9 (vi)) relies on its three ring
     stores going out as three separate ds_write_b32 in DESCENDING slot order: a lane with fewer than three spheres writes garbage
     into slots a later store of the same push overwrites -- a ds_write2_b32 / ds_write_b64 fusing two of them would let a lane's
     garbage race its neighbour's rightful value inside one instruction (nothing pinned this).  Read from the assembly

@@ -145,7 +145,7 @@ def test_thousand_sphere_scene(pt, lab, oracle, gpu, with_walls):
 def test_sweep_of_the_pooled_walk(pt, lab, oracle, gpu, rng):
     """Variant 13 leaves its lock-step DDA rounds for the sweep (pt_grid.h, grid_trips_pooled (2b)) once few lanes of a wave
     still walk: a full frame of complete waves over a 600-sphere scene (rays that stop in every cell of their way), closed and
-    open, both generators, product and lab builds (two register allocations of the same source: DESIGN.md A.12)."""
+    open, both generators, product and lab builds (two register allocations of the same source: EXACTNESS.md A.12)."""
     size = 64  # 4096 pixels: complete waves only, the sweep's precondition
     basis = pt.camera_basis(width=size, height=size)
     for walls in (True, False):
@@ -179,7 +179,7 @@ def test_grid_walk_on_rays_whose_crossings_tie(pt, lab, oracle, gpu, rng):
     eye-ray basis with corners (+-0.3125, +-0.3125, -2) and a power-of-two image, 1 sample per pixel (no jitter): every operation that
     forms a primary ray's direction is exact, |d.x| = |d.y| to the last bit on both image diagonals, and on the main diagonal the
     x- and y-crossings of the grid tie at EVERY step (on the other one within roundings of the cell boundaries).  The lock-step
-    DDA and the sweep must both walk a lattice path through such rays (the first sweep lost the cell
+    DDA and the sweep must both walk a lattice path through such rays (EXACTNESS.md A.9 (viii): the first sweep lost the cell
     behind two tied crossings).  Then the same scene with jitter (2 spp): near-diagonal rays, near-ties."""
     g = np.random.default_rng(77)
     e = 50.0

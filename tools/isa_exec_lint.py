@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Finds vector instructions placed between the start of a basic block and the `s_or_b64 exec, exec, s[..]` that re-opens the
 lanes which sat out the preceding divergent region.  The register allocator's live-range splitting of this compiler has been
-seen to put the copies of a split there: they then run for the lanes that took the region only -- for NO lane
+seen to put the copies of a split there (EXACTNESS.md A.12): they then run for the lanes that took the region only -- for NO lane
 when the region was skipped -- and the value the other lanes carry is lost.  Usage: isa_exec_lint.py file.s...
 (the library's Makefile runs it over the assembly of every build; exit status 1 = found, 2 = nothing to read;
 PT_SKIP_ISA_LINT=1 in the environment skips it.  A HEURISTIC: it knows the one shape seen so far -- a block head that holds nothing

@@ -4,7 +4,7 @@
 # Usage: tools/refresh_profiles.sh [round=r02]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r04}
+R=${1:-r05}
 python3 tools/summarise_profile.py cfg2_xorwow $R > /dev/null
 python3 tools/summarise_profile.py cfg2_philox $R > /dev/null
 python3 tools/summarise_profile.py cfg2_fast $R > /dev/null
@@ -17,7 +17,7 @@ python3 tools/update_roofline_json.py cfg2_xorwow $R cfg2_xorwow_v6
 python3 tools/update_roofline_json.py cfg2_philox $R cfg2_philox_v6
 python3 tools/update_roofline_json.py cfg2_fast $R cfg2_xorwow_v100
 python3 tools/update_roofline_json.py cfg3_xorwow $R cfg3_xorwow_v6
-python3 tools/update_roofline_json.py cfg4_v13_closed $R cfg4_xorwow_v13      # counters of a 16-spp launch: bench.py scales the count by samples
+python3 tools/update_roofline_json.py cfg4_v13_closed $R cfg4_xorwow_v13      # counters of the 256-spp frame itself (tools/pmc_cfg4.sh)
 python3 tools/update_roofline_json.py cfg4_v13_open $R cfg4open_xorwow_v13
 bash tools/isa.sh /tmp/pt_kernel_final.s
 python3 tools/issue_model.py /tmp/pt_kernel_final.s pixel_kernelILi0ELi6ELb0ELi5E profiles/$R/cfg2_xorwow.json cfg2_xorwow_v6 | cut -c1-400

@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(root, "profiles", rnd, f"{tag}.json")))
 src = f"profiles/{rnd}/{tag}.json"
 ident = {"fingerprint": d.get("fingerprint"), "num_vgprs": d.get("num_vgprs"), "source": src}
-h = d.get("hbm_bytes_per_launch")  # (absent: a profile without the TCC passes, tools/profile_cfg4.sh)
+h = d.get("hbm_bytes_per_launch")  # (absent: a profile without the TCC passes)
 tp = os.path.join(root, "profiles", "hbm_traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
 if h:
