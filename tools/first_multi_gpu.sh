@@ -2,7 +2,8 @@
 # First contact with a multi-GPU node (none was available to any round so far): everything that has only ever run with ranks
 # sharing one device, now between distinct devices over xGMI -- and BASELINE.md section 4's table filled from it.
 #   1. tests/test_mgpu_gpu.py (the distinct-device RCCL gather, the band policy between devices) and the bench multi-rank tests;
-#   2. bench.py --gpus {1,2,4,8} for cfg2 and cfg3 with both engines (one process per GPU + torch.distributed/RCCL; one process,
+#   2. bench.py --gpus {1,2,4,8} for cfg2 and cfg3 -- and the 1000-sphere frames cfg4 / cfg4open, whose row tiles are uneven
+#      (predicted x2.5 / x2.2 at N = 8 from one-GPU tile times) -- with both engines (one process per GPU + torch.distributed/RCCL; one process,
 #      pt_mgpu_* with banded exchange), every gathered frame compared bit for bit with the 1-GPU frame;
 #   3. the table: kernel ms, ms per frame (pipelined), one frame's latency, exposed gather, Msamples/s, efficiency.
 # Nothing here touches a GPU in this shell: every step is a child process.  Usage: tools/first_multi_gpu.sh [outdir=gpurun_out/mgpu]
@@ -12,8 +13,9 @@ OUT=${1:-gpurun_out/mgpu}
 mkdir -p "$OUT"
 NGPU=$(python3 -c "import torch; print(torch.cuda.device_count())")
 echo "devices: $NGPU" | tee "$OUT/summary.txt"
+python3 tools/tile_skew.py 2 > "$OUT/tile_skew.txt" 2>&1  # the one-GPU prediction from this box, to set beside the runs
 python3 -m pytest tests/test_mgpu_gpu.py tests/test_bench_multirank_gpu.py -q -x > "$OUT/tests.log" 2>&1; echo "tests rc=$? ($(tail -1 "$OUT/tests.log"))" | tee -a "$OUT/summary.txt"
-for CFG in cfg2 cfg3; do
+for CFG in cfg2 cfg3 cfg4 cfg4open; do
   python3 bench.py --gpus 1 --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-alt-rng --no-other-configs --dump "$OUT/${CFG}_n1.npy" > "$OUT/${CFG}_n1_dist.json" 2> "$OUT/${CFG}_n1_dist.err" || echo "$CFG N=1 FAILED" | tee -a "$OUT/summary.txt"
   for N in 2 4 8; do
     [ "$N" -le "$NGPU" ] || continue
@@ -29,7 +31,7 @@ import numpy as np
 out = sys.argv[1]
 print("| config | N | engine | frame = 1-GPU frame | kernel ms (slowest rank) | ms/frame pipelined | one frame latency ms | exposed gather ms | Msamples/s | efficiency |")
 print("|---|---|---|---|---|---|---|---|---|---|")
-for cfg in ("cfg2", "cfg3"):
+for cfg in ("cfg2", "cfg3", "cfg4", "cfg4open"):
     base, ref = None, None
     p1 = os.path.join(out, f"{cfg}_n1.npy")
     if os.path.exists(p1):
