@@ -165,10 +165,10 @@ if IS_LAB:
 
 
 def variants():
-    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 9, 10, 13; lab: 0..13)."""
+    """Kernel variants compiled into the loaded library (product: 0, 6, 8, 9, 10, 13, 14; lab: 0..14)."""
     out = []
     o = RendererOpts()
-    for v in range(14):
+    for v in range(15):
         lib.pt_renderer_opts_default(ctypes.byref(o))
         o.variant = v
         h = _vp()

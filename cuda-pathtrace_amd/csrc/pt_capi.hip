@@ -147,6 +147,10 @@ static int effective_variant(pt_renderer* r, int n_spheres) {
   // Many-sphere scenes: a bounce is n sphere tests; what matters is WHICH spheres are tested (the uniform grid with pooled
   // tests, variant 13: 160 ... 2048 spheres, from 72 on tiles that fill the chip) and that lanes whose path left the scene do not idle (path regeneration, variant
   // 10); a small closed tile still gains from four lanes per pixel until the speculation feedback says the scene is open.
+  // (above ~1200 spheres the cell table wants more LDS than half a CU's: the same kernel with 1024-thread workgroups, one per CU --
+  // 1024^2 x 32 spp closed / open, variant 13 | 14: 1200 spheres 13.8 / 4.3 | 12.3 / 3.6 ms, 1500: 18.0 / 6.3 | 15.6 / 5.0,
+  // 2000: 69.4 / 34.5 | 18.4 / 6.2; at 1000 spheres and 256 spp 71.1 / 22.6 | 78.7 / 25.1: profiles/r05/large_scenes.txt)
+  if (n_spheres > PT_GRID_WIDE_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 14;
   if (n_spheres >= PT_GRID_MIN_SPHERES && n_spheres <= PT_GRID_MAX_SPHERES) return 13;
   if (n_spheres >= PT_GRID_MIN_SPHERES_LARGE_TILE && n_spheres < PT_GRID_MIN_SPHERES && !r->small_tile) return 13;
   const bool xorwow = r->opts.rng_mode == PT_RNG_XORWOW;
@@ -451,7 +455,7 @@ int pt_renderer_destroy(pt_renderer* r) {
 // hand-over buffer the first time the answer is yes; an allocation failure turns chunking off for good (it is a scheduling
 // aid, never a reason for a renderer not to work).
 static uint32_t chunks_of(const pt_renderer* r, int variant) {
-  return variant == 13 ? r->chunks13 : (variant == 8 || variant == 9) ? r->chunks_split : r->chunks;
+  return (variant == 13 || variant == 14) ? r->chunks13 : (variant == 8 || variant == 9) ? r->chunks_split : r->chunks;
 }
 
 static bool chunk_buffer(pt_renderer* r, int variant, int n_spheres) {

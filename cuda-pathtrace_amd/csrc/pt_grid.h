@@ -96,22 +96,27 @@ constexpr int kGridBigGeomBytes = kGridMaxBig * (int)sizeof(float4);
 // so that bounce 0 feeds the pooled tests from it and never walks.  Link fields are 13 bits: the lists must end below 8192.
 constexpr int kPrimEntriesPerLane = 2;
 constexpr int kPrimMaxList = 5;  // 2 spheres + link, then up to 3
-constexpr int kPrimEntries = PT_GRID_BLOCK_THREADS * kPrimEntriesPerLane;
-__host__ __device__ inline int grid_max_entries(int n, bool pooled) {
+// `threads`: the workgroup size of the kernel that stages the image -- PT_GRID_BLOCK_THREADS (512: two workgroups share a CU's LDS),
+// or PT_GRID_WIDE_THREADS (1024, "variant 14": ONE workgroup per CU, the same four waves per SIMD, one image instead of two -- the
+// cell table gets the other half of the LDS, which scenes above ~1200 spheres need: at 2048 spheres 1 546 entries become 7 000)
+__host__ __device__ inline int grid_prim_entries(int threads) { return threads * kPrimEntriesPerLane; }
+__host__ __device__ inline int grid_lds_target(int threads) { return threads > PT_GRID_BLOCK_THREADS ? 2 * kPoolLdsTarget - 2048 : kPoolLdsTarget; }
+__host__ __device__ inline int grid_max_entries(int n, bool pooled, int threads = PT_GRID_BLOCK_THREADS) {
   if (!pooled) return kGridMaxEntries;  // (variant 11 does not stage the table)
-  const int fixed = kTablesF4 * (int)sizeof(float4) + (PT_GRID_BLOCK_THREADS / 64) * kPoolWaveBytes + kGridBigGeomBytes +
-                    kGridMaxBig * (int)sizeof(uint16_t) + 32 + kPrimEntries * 8;
-  int avail = kPoolLdsTarget - fixed - n * (int)sizeof(float4);
+  const int prim = grid_prim_entries(threads);
+  const int fixed = kTablesF4 * (int)sizeof(float4) + (threads / 64) * kPoolWaveBytes + kGridBigGeomBytes +
+                    kGridMaxBig * (int)sizeof(uint16_t) + 32 + prim * 8;
+  int avail = grid_lds_target(threads) - fixed - n * (int)sizeof(float4);
   if (avail < 8192) avail = 8192;  // (never with n <= kGridMaxSpheres)
   const int e = avail / 8;
-  return e > kGridMaxEntries - kPrimEntries ? kGridMaxEntries - kPrimEntries : e;
+  return e > kGridMaxEntries - prim ? kGridMaxEntries - prim : e;
 }
 
 // LDS image per workgroup: geometry of all n spheres, the geometry of the spheres outside the grid once more (contiguous: no
 // index read on the way to it), then the tables (dword aligned)
-__host__ __device__ inline size_t grid_lds_bytes(int n, bool pooled) {
+__host__ __device__ inline size_t grid_lds_bytes(int n, bool pooled, int threads = PT_GRID_BLOCK_THREADS) {
   const size_t head = (size_t)n * sizeof(float4) + kGridBigGeomBytes + kGridMaxBig * sizeof(uint16_t);
-  if (pooled) return head + (size_t)(grid_max_entries(n, true) + kPrimEntries) * 8;
+  if (pooled) return head + (size_t)(grid_max_entries(n, true, threads) + grid_prim_entries(threads)) * 8;
   return head + (kGridCellsOff - kGridStartOff);
 }
 

@@ -26,7 +26,7 @@
 // FP32, 4 + cheap sqrt/rsqrt, 5 branch-free keys, 6 straight-line speculation (one lane per pixel), 7 two samples per
 // lane, 8 four lanes per pixel, 9 two lanes per pixel, 10 per-lane path regeneration (open scenes), 11 = 10 + a
 // conservative uniform grid over the small spheres (pt_grid.h), 12 = 11 with walk and shading decoupled per lane (lab), 13 = 11 with
-// the sphere tests pooled across the lanes of a wave (pt_grid.h, "variant 13").
+// the sphere tests pooled across the lanes of a wave (pt_grid.h, "variant 13"), 14 = 13 with 1024-thread workgroups (large scenes).
 #define PT_VARIANT_AUTO (-1)  // pt_renderer_opts_default(): resolved per launch by effective_variant() in pt_capi.hip
 #define PT_DEFAULT_VARIANT 6  // the one-lane-per-pixel kernel the automatic policy uses when it does not pick variant 8
 #ifndef PT_SCREEN_MAX_SPHERES
@@ -72,6 +72,13 @@
 // four per CU (4 waves per SIMD).  512-thread workgroups share one image between eight waves; with the register cap below
 // six waves per SIMD fit (three workgroups, 108 KB).  Measured at 1000 spheres, 32 spp: 256/4 27.0 ms, see HISTORY.md B.3.
 #define PT_GRID_BLOCK_THREADS 512
+#endif
+// "variant 14" (round 5) = variant 13 with 1024-thread workgroups: one per CU (the same four waves per SIMD), ONE grid image instead of
+// two, so the cell table of a scene above ~1200 spheres gets the other half of the CU's LDS (pt_grid.h, grid_max_entries)
+#define PT_GRID_WIDE_THREADS 1024
+#define PT_LDS_WIDE_BUDGET_BYTES (159 * 1024)
+#ifndef PT_GRID_WIDE_MIN_SPHERES
+#define PT_GRID_WIDE_MIN_SPHERES 1200
 #endif
 #ifndef PT_GRID_MIN_WAVES
 #define PT_GRID_MIN_WAVES 6  // __launch_bounds__ 2nd argument of the grid kernel: <= 80 VGPRs
@@ -191,7 +198,8 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
 bool pt_kernel_has_frames(int variant, int n_spheres, int max_bounces, bool planar);
 hipError_t pt_launch_frames_kernel(const FramesKernelArgs& fa, int rng_mode, hipStream_t stream);
 hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */,
-                                bool pooled /* for variant 13's LDS image (fewer cells at large n) */, hipStream_t stream);
+                                bool pooled /* for variant 13's LDS image (fewer cells at large n) */, hipStream_t stream,
+                                int threads = PT_GRID_BLOCK_THREADS /* workgroup size of the kernel that will stage the grid */);
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);

@@ -17,8 +17,8 @@ namespace pt {
 // REFB != 0 builds the kernel for the reference's own scene size -- 9 spheres (Scene.h:23) -- and a fixed bounce cap as
 // compile-time constants: REFB = 5 is the reference's MAX_BOUNCES (pathtrace.cu:7), REFB = 8 the interactive configuration
 // (BASELINE.json configs[4]).  No generic loops, no index-width arithmetic, and a hot loop that is a third smaller.
-template <int VAR>
-constexpr int kBlockThreads = (VAR == 11 || VAR == 12 || VAR == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
+template <int VAR, bool WIDE = false>
+constexpr int kBlockThreads = (VAR == 13 && WIDE) ? PT_GRID_WIDE_THREADS : (VAR == 11 || VAR == 12 || VAR == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
 template <int VAR>
 constexpr int kMinWaves = (VAR == 11) ? PT_GRID_MIN_WAVES : (VAR == 13) ? PT_POOL_MIN_WAVES : (VAR == 12) ? PT_GRID12_MIN_WAVES : PT_MIN_WAVES;
 
@@ -101,8 +101,9 @@ template <bool FRAMES> __device__ __forceinline__ PixelKernelArgs& base_args(typ
   if constexpr (FRAMES) return args.base; else return args;
 }
 
-template <int RNG, int VAR, bool LEAN = false, int REFB = 0, bool FRAMES = false>
-__global__ void __launch_bounds__(kBlockThreads<VAR>, ((FRAMES && RNG == PT_RNG_XORWOW) ? PT_MIN_WAVES : kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR
+// WIDE (variant 13 only; the launcher's "variant 14"): 1024-thread workgroups, one per CU -- pt_grid.h, grid_max_entries
+template <int RNG, int VAR, bool LEAN = false, int REFB = 0, bool FRAMES = false, bool WIDE = false>
+__global__ void __launch_bounds__((kBlockThreads<VAR, WIDE>), ((FRAMES && RNG == PT_RNG_XORWOW) ? PT_MIN_WAVES : kMinWavesR<VAR, REFB, RNG>)) PT_KERNEL_ATTR
 pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch has one workgroup per pixel block for all its frames: the
                                                            // interactive shape fills four of a CU's five slots, so that build takes 128 registers)
   PixelKernelArgs& a = base_args<FRAMES>(args);
@@ -125,7 +126,7 @@ pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch ha
   };
   if constexpr (FRAMES) fr_count = args.frames;
   if constexpr (FRAME_GRID) {
-    const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
+    const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR, WIDE> - 1) / kBlockThreads<VAR, WIDE>;
     fr = blockIdx.x / n_blocks;  // (workgroup-uniform)
     first_block = blockIdx.x - fr * n_blocks;
     load_camera(fr);  // before the scene image is staged for this frame's eye
@@ -153,7 +154,7 @@ pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch ha
     grid = stage_grid<VAR == 13>(a.spheres, a.n_spheres, a.accel, lds_scene + a.scene_lds_f4);  // after the two small tables
     sc.grid = &grid;
     if constexpr (VAR == 13)  // the test pool of each wave follows the grid image (16-byte aligned)
-      sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres, true) + 15) & ~(size_t)15);
+      sc.pool = reinterpret_cast<char*>(lds_scene + a.scene_lds_f4) + ((grid_lds_bytes(a.n_spheres, true, kBlockThreads<VAR, WIDE>) + 15) & ~(size_t)15);
   }
 
   // Sample chunking (REF builds of variant 6, variant 13): workgroup blockIdx.x = chunk * n_blocks + block renders samples
@@ -167,13 +168,13 @@ pixel_kernel(typename KernelArgsOf<FRAMES>::type args) {  // (an XORWOW batch ha
   uint32_t block_id = FRAMES ? first_block : blockIdx.x, chunk = 0u, n_chunks = 1u;
   if constexpr (CHUNKS) {
     if (a.chunks > 1u) {
-      const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR> - 1) / kBlockThreads<VAR>;
+      const uint32_t n_blocks = (a.tile_pixels + kBlockThreads<VAR, WIDE> - 1) / kBlockThreads<VAR, WIDE>;
       n_chunks = a.chunks;
       chunk = blockIdx.x / n_blocks;
       block_id = blockIdx.x - chunk * n_blocks;
     }
   }
-  const uint32_t tp = block_id * kBlockThreads<VAR> + threadIdx.x;  // pixel index inside the tile
+  const uint32_t tp = block_id * kBlockThreads<VAR, WIDE> + threadIdx.x;  // pixel index inside the tile
   const bool active = tp < a.tile_pixels;  // lanes past the tile stay for the cooperative epilogue
   const int row = a.row_begin + (int)(tp / (uint32_t)a.width);
   const int col = (int)(tp % (uint32_t)a.width);
@@ -951,7 +952,7 @@ __global__ void __launch_bounds__(PT_BLOCK_THREADS)
 // LDS layout of a launch (pt_scene_lds.h): many-sphere scenes keep only the geometry in LDS
 // (variants 6, 8 and 10 -- the ones the automatic policy uses -- are also built for that layout)
 static inline bool lds_lean(int n, int variant) {
-  return variant == 11 || variant == 12 || variant == 13 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
+  return variant == 11 || variant == 12 || variant == 13 || variant == 14 || (n > PT_SCREEN_MAX_SPHERES && (variant == 6 || variant == 8 || variant == 10));
 }
 static inline bool is_split(int variant) { return variant == 8 || variant == 9; }
 static inline size_t scene_lds_f4(int n, int variant) {
@@ -962,8 +963,10 @@ static inline size_t scene_lds_f4(int n, int variant) {
 // split kernels' exchange records
 static inline size_t tail_lds_bytes(int n, int variant) {
   if (variant == 11 || variant == 12) return n <= pt::kGridMaxSpheres ? pt::grid_lds_bytes(n, false) : 64;  // geometry + grid tables instead of the epilogue slice
-  if (variant == 13)  // + per wave the test ring and the owners' result slots
-    return (n <= pt::kGridMaxSpheres ? ((pt::grid_lds_bytes(n, true) + 15) & ~(size_t)15) : 64) + (PT_GRID_BLOCK_THREADS / 64) * pt::kPoolWaveBytes;
+  if (variant == 13 || variant == 14) {  // + per wave the test ring and the owners' result slots
+    const int threads = variant == 14 ? PT_GRID_WIDE_THREADS : PT_GRID_BLOCK_THREADS;
+    return (n <= pt::kGridMaxSpheres ? ((pt::grid_lds_bytes(n, true, threads) + 15) & ~(size_t)15) : 64) + (threads / 64) * pt::kPoolWaveBytes;
+  }
   if (is_split(variant)) return (PT_BLOCK_THREADS / 64) * 64 * pt::kRecWords * sizeof(float);
   return (PT_BLOCK_THREADS / 64) * 64 * 14 * sizeof(float);
 }
@@ -999,6 +1002,7 @@ static pixel_kernel_fn select_kernel(int rng_mode, int variant, bool lean, int r
       case 8: return philox ? pt::pixel_kernel_split<PT_RNG_PHILOX, 4, true> : pt::pixel_kernel_split<PT_RNG_XORWOW, 4, true>;
       case 10: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 10, true> : pt::pixel_kernel<PT_RNG_XORWOW, 10, true>;
       case 13: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 13, true> : pt::pixel_kernel<PT_RNG_XORWOW, 13, true>;
+      case 14: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 13, true, 0, false, true> : pt::pixel_kernel<PT_RNG_XORWOW, 13, true, 0, false, true>;
 #if PT_BUILD_EXPERIMENTS  // variant 11 (the grid walk with every lane testing its own spheres): superseded by 13, kept for A/B
       case 11: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 11, true> : pt::pixel_kernel<PT_RNG_XORWOW, 11, true>;
       case 12: return philox ? pt::pixel_kernel<PT_RNG_PHILOX, 12, true> : pt::pixel_kernel<PT_RNG_XORWOW, 12, true>;
@@ -1048,16 +1052,18 @@ extern "C" int pt_debug_grid_stats(unsigned long long out[8], int reset) {
 }
 #endif
 
-int pt_kernel_num_variants(void) { return 14; }
+int pt_kernel_num_variants(void) { return 15; }
 
-int pt_kernel_block_threads(int variant) { return (variant == 11 || variant == 12 || variant == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS; }
+int pt_kernel_block_threads(int variant) {
+  return variant == 14 ? PT_GRID_WIDE_THREADS : (variant == 11 || variant == 12 || variant == 13) ? PT_GRID_BLOCK_THREADS : PT_BLOCK_THREADS;
+}
 
 bool pt_kernel_has_variant(int variant) {
-  if (variant < 0 || variant >= 14) return false;
+  if (variant < 0 || variant >= 15) return false;
 #if PT_BUILD_EXPERIMENTS
   return true;
 #else
-  return variant == 0 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 13;
+  return variant == 0 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 13 || variant == 14;
 #endif
 }
 
@@ -1074,16 +1080,16 @@ size_t pt_kernel_lds_bytes(int n_spheres, int variant) { return scene_lds_bytes(
 int pt_kernel_max_spheres(int variant) {
   // variants with a lean build stage nothing for big scenes; the others are bounded by their LDS image
   const size_t tail = tail_lds_bytes(0, variant);
-  if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12 || variant == 13) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
+  if (variant == 6 || variant == 8 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14) return 1 << 26;  // byte offsets of the 40-byte records stay inside 32 bits
   const size_t fixed = tail + pt::kTablesF4 * sizeof(float4);
   if (variant == 3) return (int)((PT_LDS_BUDGET_BYTES - fixed - 2 * sizeof(float4)) / (5 * sizeof(float4)));
   return (int)((PT_LDS_BUDGET_BYTES - fixed) / (4 * sizeof(float4)));
 }
 
-hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, bool pooled, hipStream_t stream) {
+hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye, bool pooled, hipStream_t stream, int threads) {
   // (table entries the LDS image of the kernel that will walk this grid has room for)
   hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel, eye ? eye[0] : 0.0f,
-                     eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0, pt::grid_max_entries(n, pooled));
+                     eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0, pt::grid_max_entries(n, pooled, threads));
   return hipGetLastError();
 }
 
@@ -1091,7 +1097,7 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
 bool pt_kernel_chunked(int variant, int n_spheres, int max_bounces, bool planar, int spp, uint32_t chunks) {
   return (((variant == 6 || variant == 8 || variant == 9) && !lds_lean(n_spheres, variant) && ref_config(n_spheres, max_bounces, variant, planar)) || variant == 13) && chunks > 1u &&
          chunks <= (uint32_t)PT_CHUNKS_MAX && spp >= 2 * (int)chunks &&
-         (spp + (int)chunks - 1) / (int)chunks <= (variant == 13 ? PT_CHUNK_MAX_SAMPLES_GRID : PT_CHUNK_MAX_SAMPLES);
+         (spp + (int)chunks - 1) / (int)chunks <= ((variant == 13 || variant == 14) ? PT_CHUNK_MAX_SAMPLES_GRID : PT_CHUNK_MAX_SAMPLES);
 }
 
 hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int variant, hipStream_t stream) {
@@ -1102,14 +1108,16 @@ hipError_t pt_launch_pixel_kernel(const PixelKernelArgs& a, int rng_mode, int va
   b.scene_lds_f4 = (uint32_t)scene_lds_f4(a.n_spheres, variant);
   b.prio = (a.spp >= PT_PRIO_MIN_SPP || a.prio != 0u) ? 1u : 0u;  // long waves always; short ones when the caller says the frame is one round
   const size_t lds = scene_lds_bytes(a.n_spheres, variant);
-  if (lds > PT_LDS_BUDGET_BYTES) return hipErrorInvalidValue;
+  const size_t lds_budget = variant == 14 ? (size_t)PT_LDS_WIDE_BUDGET_BYTES : (size_t)PT_LDS_BUDGET_BYTES;
+  if (lds > lds_budget) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BUDGET_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
     if (e != hipSuccess) return e;
   }
-  if (variant == 11 || variant == 12 || variant == 13) {  // this frame's grid (the scene may have changed since the last one)
+  if (variant == 11 || variant == 12 || variant == 13 || variant == 14) {  // this frame's grid (the scene may have changed since the last one)
     if (!a.accel) return hipErrorInvalidValue;
-    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, variant == 13, stream);
+    hipError_t e = pt_launch_build_grid(a.spheres, a.n_spheres, const_cast<uint32_t*>(a.accel), a.eye, variant == 13 || variant == 14, stream,
+                                        pt_kernel_block_threads(variant));
     if (e != hipSuccess) return e;
   }
   const uint64_t lanes = (uint64_t)a.tile_pixels * (uint64_t)(variant == 8 ? 4 : variant == 9 ? 2 : 1);

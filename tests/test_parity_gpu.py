@@ -58,7 +58,7 @@ def _all_variants(pt, lab):
     """(module, variant) for every kernel variant: the product library's own (0, 6, 8, 9, 10, 13) from libptcore.so,
     the experimental and superseded ones (1-5, 7, 11, 12) from libptcore_lab.so."""
     prod = pt.variants()
-    assert prod == [0, 6, 8, 9, 10, 13] and lab.variants() == list(range(14))
+    assert prod == [0, 6, 8, 9, 10, 13, 14] and lab.variants() == list(range(15))
     return [(pt, v) for v in prod] + [(lab, v) for v in lab.variants() if v not in prod]
 
 
@@ -742,3 +742,21 @@ def test_cli_preview_is_the_display_packed_frame(pt, oracle, gpu, tmp_path):
     ref = oracle.render(32, 32, 8, spheres=pt.scene_cornell(), basis=pt.camera_basis(width=32, height=32))
     want = oracle.display_pack(ref)[..., 2].copy().view(np.uint8).reshape(32, 32, 4)[..., :3]
     assert np.array_equal(rgb, want)
+
+
+def test_wide_grid_kernel_on_large_scenes(pt, oracle, gpu):
+    """Variant 14 = variant 13 with 1024-thread workgroups (one per CU: the cell table of a scene above ~1200 spheres gets the other half
+    of the LDS).  1500 and 2048 spheres, closed and open, both generators, a frame of ragged 1024-pixel blocks; and the automatic
+    policy picks it for such scenes, variant 13 up to 1200 spheres."""
+    w, h, spp = 200, 88, 4  # 17 600 pixels: 17 full workgroups and one with 192 of its 1024 lanes
+    basis = pt.camera_basis(width=w, height=h)
+    for n, walls, rng in ((1500, True, 0), (2048, False, 1), (2048, True, 0)):
+        sph = pt.scene_random(n, seed=21, with_walls=walls)
+        ref = oracle.render(w, h, spp, spheres=sph, basis=basis, rng_mode=rng)
+        for v in (14, 13):
+            img, _ = pt.render_frame(w, h, spp, spheres=sph, basis=basis, rng_mode=rng, variant=v)
+            assert_bit_exact(img, ref, f"{n} spheres walls={walls} rng {rng} variant {v}")
+    r = pt.Renderer(1024, 1024, 4)
+    assert r.kernel_info(1500)["variant"] == 14 and r.kernel_info(1500)["block_threads"] == 1024
+    assert r.kernel_info(1000)["variant"] == 13 and r.kernel_info(2049)["variant"] == 10
+    r.destroy()

@@ -52,7 +52,7 @@ for seed in range(first, first + n_cases):
     mb = 8 if seed % 3 == 0 else 5
     with np.errstate(all="ignore"):
         ref = oracle.render(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, threads=8, max_bounces=mb)
-    variants = (6, 8, 9, None) if n == 9 else ((0, 6, 8, 10, None) if n < 100 else (10, 13, None))
+    variants = (6, 8, 9, None) if n == 9 else ((0, 6, 8, 10, None) if n < 100 else (10, 13, 14, None))
     for v in variants:
         img, _ = pt.render_frame(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, variant=v, max_bounces=mb)
         a, b = img.view(np.uint32), ref.view(np.uint32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Soak for the many-sphere kernel (variant 13: grid walk, pooled tests, the sweep): random scenes of 72-2048 spheres -- radii
+"""Soak for the many-sphere kernel (variants 13 and 14: grid walk, pooled tests, the sweep, per-pixel primary lists): random scenes of 72-2048 spheres -- radii
 from one size to two decades apart, clustered or uniform centres, with or without the walls -- random cameras inside and outside
-the cloud, both generators, 1-8 bounces, frames of complete waves; variant 13 and the automatic choice against the CPU oracle,
+the cloud, both generators, 1-8 bounces, frames of complete waves; variants 13, 14 and the automatic choice against the CPU oracle,
 BIT FOR BIT.  Usage: many_soak.py [n_cases=200] [first_seed=0] [large]   (large: frames of 128-256 pixels a side)"""
 import json, os, sys, time
 import numpy as np
@@ -37,7 +37,7 @@ for seed in range(first, first + n_cases):
     basis = pt.camera_basis(eye, float(rng.uniform(-130, -50)), float(rng.uniform(-25, 25)), size, size)
     mode, spp, mb = int(seed % 2), int(rng.integers(1, 5)), int(rng.integers(1, 9))
     ref = oracle.render(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, threads=16)
-    for v in (13, None):
+    for v in (13, 14, None):  # 14 = 13 with 1024-thread workgroups (the automatic choice above 1200 spheres on large tiles)
         img, _ = pt.render_frame(size, size, spp, spheres=sc, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
         neq = int((img.view(np.uint32) != ref.view(np.uint32)).sum())
         floats += img.size
