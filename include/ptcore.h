@@ -79,7 +79,7 @@ typedef struct pt_renderer_opts {
                         /*   calls like Renderer::d_states (Renderer.h:17,37; pathtrace.cu:212,256); default 1 */
   int32_t variant;      /* kernel variant, all produce identical bits: -1 (default) = automatic    */
                         /*   (by scene size, tile size and generator), 0 = literal transcription,  */
-                        /*   6, 8, 9, 10, 13 see DESIGN.md section 3 (1-5, 7, 11, 12: libptcore_lab.so)  */
+                        /*   6, 8, 9, 10, 13, 14 see DESIGN.md section 3 (1-5, 7, 11, 12: libptcore_lab.so) */
   int32_t layout;       /* PT_LAYOUT_INTERLEAVED (default): the reference's [row][col][14] buffer  */
                         /*   (pathtrace.cu:240-254); PT_LAYOUT_PLANAR: [14][rows][width] of this   */
                         /*   renderer's tile -- same values, channel-first like a torch NCHW tensor */
