@@ -601,7 +601,8 @@ def test_automatic_variant_policy(pt, lab, oracle, gpu):
     big = pt.Renderer(1024, 1024, 8)
     assert big.kernel_info(9)["variant"] == 6
     # many-sphere scenes: the grid kernel from 160 spheres on any tile, from 72 on a tile that fills the chip (tools/grid_threshold.py)
-    assert [big.kernel_info(n)["variant"] for n in (11, 71, 72, 159, 160, 2048, 2049)] == [10, 10, 13, 13, 13, 13, 10]
+    # ... with 1024-thread workgroups (variant 14) above 1200 spheres (tools/large_scenes.py)
+    assert [big.kernel_info(n)["variant"] for n in (11, 71, 72, 159, 160, 1200, 1201, 2048, 2049)] == [10, 10, 13, 13, 13, 13, 14, 14, 10]
     big.destroy()
     small = pt.Renderer(128, 128, 8)
     assert [small.kernel_info(n)["variant"] for n in (71, 72, 159, 160)] == [8, 8, 8, 13]

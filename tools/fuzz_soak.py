@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: N random scenes/cameras/generators (same generator as tests/test_parity_gpu.py's fuzz
-test), variants 0, 6, 8, 10, 13 and the automatic choice against the CPU oracle, bit for bit.
+test), variants 0, 6, 8, 10, 13, 14 and the automatic choice against the CPU oracle, bit for bit.
 Usage: fuzz_soak.py [n_seeds] [first_seed]"""
 import json, os, sys, time
 import numpy as np
@@ -22,7 +22,7 @@ for seed in range(first, first + n_seeds):
     basis = pt.camera_basis(eye, float(rng.uniform(-120, -60)), float(rng.uniform(-20, 20)), size, size)
     mode, spp, mb = int(seed % 2), int(rng.integers(1, 12)), int(rng.integers(1, 9))
     ref = oracle.render(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, threads=8)
-    for v in (0, 6, 8, 10, 13, None):
+    for v in (0, 6, 8, 10, 13, 14, None):
         img, _ = pt.render_frame(size, size, spp, spheres=scene, basis=basis, eye=eye, rng_mode=mode, max_bounces=mb, variant=v)
         neq = int((img.view(np.uint32) != ref.view(np.uint32)).sum())
         floats += img.size
@@ -30,6 +30,6 @@ for seed in range(first, first + n_seeds):
             bad.append({"seed": seed, "variant": v, "floats_different": neq})
     if (seed - first) % 100 == 99:
         print(f"{seed - first + 1} seeds, {floats} floats compared, {len(bad)} mismatching (seed, variant) pairs, {time.time()-t0:.0f} s", flush=True)
-res = {"seeds": n_seeds, "first_seed": first, "variants": [0, 6, 8, 10, 13, "auto"], "floats_compared": floats, "mismatches": bad}
+res = {"seeds": n_seeds, "first_seed": first, "variants": [0, 6, 8, 10, 13, 14, "auto"], "floats_compared": floats, "mismatches": bad}
 print(json.dumps(res))
 sys.exit(1 if bad else 0)

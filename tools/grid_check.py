@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Variant 11 (uniform grid) against variant 10 (brute force) at full resolution: bit-for-bit comparison of
+"""Variants 11 (uniform grid, lab), 13 and 14 (pooled grid kernel, 512- and 1024-thread workgroups) against variant 10 (brute force) at full resolution: bit-for-bit comparison of
 whole frames on many-sphere scenes with different sphere counts, radii and cameras.  Usage: grid_check.py [spp=8]"""
 import json, os, sys
 import numpy as np
@@ -71,9 +71,11 @@ for name, scene in cases:
         a, ms10 = frame(scene, basis, eye, 10, mode)
         b, ms11 = frame(scene, basis, eye, 11, mode)
         c, ms13 = frame(scene, basis, eye, 13, mode)
-        diff = int((a.view(np.uint32) != b.view(np.uint32)).sum()) + int((a.view(np.uint32) != c.view(np.uint32)).sum())
+        e, ms14 = frame(scene, basis, eye, 14, mode)
+        diff = (int((a.view(np.uint32) != b.view(np.uint32)).sum()) + int((a.view(np.uint32) != c.view(np.uint32)).sum()) +
+                int((a.view(np.uint32) != e.view(np.uint32)).sum()))
         h = pt.grid_header(scene)
-        rec = {"case": name, "camera": ci, "rng": mode, "floats_different": diff, "ms_v10": round(ms10, 2), "ms_v11": round(ms11, 2), "ms_v13": round(ms13, 2),
+        rec = {"case": name, "camera": ci, "rng": mode, "floats_different": diff, "ms_v10": round(ms10, 2), "ms_v11": round(ms11, 2), "ms_v13": round(ms13, 2), "ms_v14": round(ms14, 2),
                "grid": {"valid": h["valid"], "dims": h["dims"], "n_items": h["n_items"], "n_big": h["n_big"]}}
         out.append(rec)
         print(json.dumps(rec), flush=True)
