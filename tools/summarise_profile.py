@@ -17,7 +17,14 @@ dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 out = {"tag": tag}
 
-st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+def newest(paths):
+    """gpurun MERGES a run's files into the local gpurun_out/ without removing what an earlier run left there (rocprofv3 names
+    its files by pid): only the newest file of a pass belongs to the run being summarised."""
+    paths = sorted(paths, key=os.path.getmtime)
+    return paths[-1:]
+
+
+st = newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True))
 if st:
     rows = list(csv.DictReader(open(st[0])))
     out["kernel_stats"] = rows
@@ -25,7 +32,7 @@ if st:
 
 def pmc(sub):
     acc = {}
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if "pixel_kernel" not in r["Kernel_Name"]:
                 continue
