@@ -19,6 +19,7 @@ python3 tools/update_roofline_json.py cfg2_fast $R cfg2_xorwow_v100
 python3 tools/update_roofline_json.py cfg3_xorwow $R cfg3_xorwow_v6
 python3 tools/update_roofline_json.py cfg4_v13_closed $R cfg4_xorwow_v13      # counters of the 256-spp frame itself (tools/pmc_cfg4.sh)
 python3 tools/update_roofline_json.py cfg4_v13_open $R cfg4open_xorwow_v13
+python3 tools/update_roofline_json.py cfg5_xorwow $R cfg5_xorwow_v6
 bash tools/isa.sh /tmp/pt_kernel_final.s
 python3 tools/issue_model.py /tmp/pt_kernel_final.s pixel_kernelILi0ELi6ELb0ELi5E profiles/$R/cfg2_xorwow.json cfg2_xorwow_v6 | cut -c1-400
 python3 tools/issue_model.py /tmp/pt_kernel_final.s pixel_kernelILi0ELi6ELb0ELi5E profiles/$R/cfg3_xorwow.json cfg3_xorwow_v6 | cut -c1-200
