@@ -384,6 +384,7 @@ def main():
     d_scene = torch.from_numpy(spheres.view("u1").reshape(-1).copy()).to(device)
     stream = torch.cuda.current_stream()
     total_samples = WIDTH * HEIGHT * spp * args.steps
+    repaired = None  # (the native engine's band renderers are asked by pt_mgpu_render itself: a broken chain fails that call)
 
     if native:
         # ---- one process, libptcore's own multi-GPU entry (pt_mgpu_*) -------------------------------------
@@ -464,7 +465,7 @@ def main():
                 step(events[k])
             sync()
             dt = time.perf_counter() - t0
-            rend.check()  # an enqueued frame whose sample-chunk chain broke is an error of this run, not of nobody
+            repaired = rend.check()  # an enqueued frame whose sample-chunk chain broke is an error of this run, not of nobody
             k_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
             # ONE frame on its own (N > 1): render, then the gather, nothing overlapped -- the latency a caller of the synchronous
             # Renderer::Render sees ("ms/frame incl. RCCL gather"), next to the pipelined ms_per_step above
@@ -615,6 +616,7 @@ def main():
             "fast_mode": fast,
             "other_configs": others,
             "kernel_info": dict(ki, fingerprint=pt.build_fingerprint()),
+            "repaired_frames": repaired,  # frames whose broken sample-chunk chain pt_renderer_render repaired in place (normally 0)
         }
         if latency:  # N > 1: one unpipelined frame (render + gather) and what the gather adds to the slowest rank's kernel
             out.update(latency)
