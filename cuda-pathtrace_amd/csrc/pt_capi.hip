@@ -387,7 +387,7 @@ int pt_renderer_create(int width, int height, int samples_per_pixel, int threads
         const uint64_t groups = ((uint64_t)r->tile_pixels + 511u) / 512u;
         const uint64_t rounds = (groups + resident - 1) / resident;
         want13 = rounds >= 32 ? 1 : (int)((32 + rounds - 1) / rounds);
-        if (want13 > 8) want13 = 8;
+        if (want13 > PT_CHUNKS_GRID_MAX) want13 = PT_CHUNKS_GRID_MAX;
         while (want13 >= 2 && r->spp / want13 < 32) want13 /= 2;
         // Round 5: a tile whose workgroups fill at most HALF the chip's slots gains nothing from chunk workgroups -- they are resident
         // at once and only wait for their predecessors, in slots the working ones could have had to themselves (rows 512..640 of

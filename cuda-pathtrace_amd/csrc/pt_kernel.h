@@ -94,6 +94,9 @@
 #ifndef PT_POOL_HELPERS
 #define PT_POOL_HELPERS 1  // variant 13: lanes whose pixel is finished stay in the loop as helpers of the wave's pooled sphere tests (pt_kernel.hip)
 #endif
+#ifndef PT_V13_WELFORD_TABLE
+#define PT_V13_WELFORD_TABLE 1  // variant 13: the Welford updates share one count and take delta / n through the 1/n table like the reference-scene kernels
+#endif
 #ifndef PT_V13_DEAD_END
 #define PT_V13_DEAD_END 1  // variant 13: the last bounce of a path forms no next ray and skips the winner's FP64 step (pt_trace.h, pt_grid.h)
 #endif
@@ -169,6 +172,11 @@ struct FramesKernelArgs {
 #define PT_CHUNKS_SMALL_TILE 6  // ... and of at most 3.25
 #define PT_CHUNKS_SPLIT 4       // ... in the split kernels (variants 8, 9)
 #define PT_CHUNKS_MAX 16
+#ifndef PT_CHUNKS_GRID_MAX
+// ... of the pooled grid kernel: round 5's kernel is flat from 4 to 8 chunks (closed / open at 256 spp, 4 | 6 | 8: 71.4 | 71.2 | 71.3 and
+// 22.4 | 22.3 | 22.6 ms, profiles/r05/cfg4_ab.txt) and every hand-over is 208 B of traffic per pixel: four
+#define PT_CHUNKS_GRID_MAX 4
+#endif
 // A chunk may only be as long as keeps the worst chained wait (all chunks of a block co-resident: chunk k waits k chunk
 // durations) far inside the wait limit: at most this many samples per chunk (about 50 ms of kernel time on an MI355X)
 #define PT_CHUNK_MAX_SAMPLES 4096

@@ -363,7 +363,7 @@ frame_top:
       if (live & (escaped | (n >= a.max_bounces))) {
         if (!escaped) {
           L.color = L.color + color;                 // :198
-          if (sc.lean) welford_update(var[0], luminance(color)); else welford_update(var[0], luminance(color), sc.rcpn);  // :200
+          if (sc.lean && !(VAR == 13 && PT_V13_WELFORD_TABLE)) welford_update(var[0], luminance(color)); else welford_update(var[0], luminance(color), sc.rcpn);  // :200
         }
         i++;
         n = 0;

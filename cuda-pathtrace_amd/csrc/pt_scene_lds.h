@@ -89,7 +89,7 @@ __device__ __forceinline__ SceneLds stage_scene(const pt_sphere* __restrict__ sp
       const float a = __uint_as_float(0x3F800000u - (uint32_t)kUnitTabHalf + (uint32_t)i);
       s.rden1[i] = ray_const_rden(2.0 * (double)a);
     }
-    const int counts = lean ? 0 : (spp < kRcpTab ? spp : kRcpTab);  // a pixel's accumulators never count beyond spp; lean layouts divide
+    const int counts = spp < kRcpTab ? spp : kRcpTab;  // a pixel's accumulators never count beyond spp (lean layouts: the grid kernel reads it)
     for (int i = threadIdx.x; i < counts; i += blockDim.x) s.rcpn[i] = 1.0f / (float)(i + 1);  // the division of :52 itself
     if (threadIdx.x == 0) s.rcpn[kRcpTab] = qnan;
   }

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool bounce_shade(TraceOutput& L, const SceneLds& sc,
     L.normal = L.normal + normal;
     L.albedo = L.albedo + scol;
     L.depth += t;
-    if (VAR >= 6 && !sc.lean) {  // (the many-sphere kernels keep the division: their registers are scarcer than their cycles here)
+    if (VAR >= 6 && (!sc.lean || (VAR == 13 && PT_V13_WELFORD_TABLE))) {  // (the lean brute-force kernels keep the division; the grid kernel shares ONE count and the table)
       welford_update3(var[1], var[2], var[3], luminance(normal), lum_col, t, sc.rcpn);
     } else {
       welford_update(var[1], luminance(normal));

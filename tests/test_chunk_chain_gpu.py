@@ -65,7 +65,7 @@ def test_pooled_grid_kernel_chunks(pt, gpu, oracle, rng):
             r.destroy()
     # the automatic policy: a frame of few rounds of workgroups is chunked, a frame of many is not
     r = pt.Renderer(1024, 1024, 256)
-    assert r.kernel_info(1000)["variant"] == 13 and r.kernel_info(1000)["grid_blocks"] == 8 * (1024 * 1024 // 512)
+    assert r.kernel_info(1000)["variant"] == 13 and r.kernel_info(1000)["grid_blocks"] == 4 * (1024 * 1024 // 512)
     r.destroy()
     r = pt.Renderer(4096, 4096, 64)
     assert r.kernel_info(1000)["grid_blocks"] == 4096 * 4096 // 512  # 32768 workgroups = 64 rounds already
