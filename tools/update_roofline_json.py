@@ -24,7 +24,11 @@ if v:
     c = d["pmc_per_launch_avg"]
     vp = os.path.join(root, "profiles", "valu_roofline.json")
     r = json.load(open(vp)) if os.path.exists(vp) else {}
-    samples = d.get("samples_per_launch") or 2 ** 30
+    samples = d.get("samples_per_launch")
+    if not samples:  # a bench.py profile: the samples of one step, from the metric's "<W>x<H>x<spp>spp"
+        import re
+        m = re.search(r"(\d+)x(\d+)x(\d+)spp", (d.get("bench_line_under_profiler") or {}).get("metric", ""))
+        samples = int(m.group(1)) * int(m.group(2)) * int(m.group(3)) if m else 2 ** 30
     r[key] = dict({"valu_insts_per_launch": v["insts_per_launch"], "kernel_ms": v["kernel_ms"], "samples_per_launch": samples,
                    "achieved_ginst_per_s": v["achieved_ginst_per_s"], "peak_ginst_per_s": v["peak_ginst_per_s"], "frac": v["frac"],
                    "flops_fp32_per_launch": (v["flops_fp32"] or 0) * 64, "flops_fp64_per_launch": (v["flops_fp64"] or 0) * 64,
