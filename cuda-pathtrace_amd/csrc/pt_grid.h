@@ -66,7 +66,8 @@ struct GridHeader {  // 64 bytes, written by build_grid_kernel
   float cz, far2;  // grid centre and (5E)^2: rays starting farther away are not admitted
   uint32_t n_big, n_items;  // n_big: bits 0-15 = spheres outside the grid, bits 16-31 = entries of the pooled walk's table (cells + chained)
   float r_small, r_big;     // a sphere is registered in the grid iff r_small <= radius <= r_big (pt_primlist.h classifies with the same compare)
-  uint32_t prim_base, pad_; // variant 13: table index of the per-pixel primary-ray lists (behind the room for cells + chained entries)
+  uint32_t prim_base, n_emis; // variant 13: table index of the per-pixel primary-ray lists (behind the room for cells + chained entries);
+                              // emitting spheres inside the grid (0xFFFF: more than kGridMaxEmis -- no last-bounce shortcut)
 };
 static_assert(sizeof(GridHeader) == 80, "GridHeader layout");
 
@@ -81,7 +82,11 @@ constexpr size_t kGridBigOff = sizeof(GridHeader);
 constexpr size_t kGridStartOff = kGridBigOff + kGridMaxBig * sizeof(uint16_t);
 constexpr size_t kGridItemsOff = kGridStartOff + (kGridMaxCells + 2) * sizeof(uint16_t);
 constexpr size_t kGridCellsOff = (kGridItemsOff + kGridMaxItems * sizeof(uint16_t) + 7) & ~(size_t)7;
-constexpr size_t kGridAccelBytes = kGridCellsOff + (size_t)(kGridMaxEntries + 1) * 2 * sizeof(uint32_t);
+// Round 5 (grid_last_shortcut): which spheres EMIT -- a bitmap over all spheres and the list of the emitting spheres inside the grid
+constexpr int kGridMaxEmis = 16;                                  // more emitting grid spheres than this: the shortcut is off
+constexpr int kGridEmisWords = PT_GRID_MAX_SPHERES / 32 + kGridMaxEmis / 2;  // bitmap, then the list (u16)
+constexpr size_t kGridEmisOff = kGridCellsOff + (size_t)(kGridMaxEntries + 1) * 2 * sizeof(uint32_t);
+constexpr size_t kGridAccelBytes = kGridEmisOff + (size_t)kGridEmisWords * sizeof(uint32_t);
 
 // How many table entries the pooled kernel's grid may have (cells + chained entries).  Variant 11's image has room for the maxima
 // of its own tables; variant 13's (8 bytes per entry, no registration list, plus 2.75 KB of test pool per wave) is sized so that
@@ -105,7 +110,7 @@ __host__ __device__ inline int grid_max_entries(int n, bool pooled, int threads 
   if (!pooled) return kGridMaxEntries;  // (variant 11 does not stage the table)
   const int prim = grid_prim_entries(threads);
   const int fixed = kTablesF4 * (int)sizeof(float4) + (threads / 64) * kPoolWaveBytes + kGridBigGeomBytes +
-                    kGridMaxBig * (int)sizeof(uint16_t) + 32 + prim * 8;
+                    kGridMaxBig * (int)sizeof(uint16_t) + 32 + prim * 8 + kGridEmisWords * 4;
   int avail = grid_lds_target(threads) - fixed - n * (int)sizeof(float4);
   if (avail < 8192) avail = 8192;  // (never with n <= kGridMaxSpheres)
   const int e = avail / 8;
@@ -116,7 +121,7 @@ __host__ __device__ inline int grid_max_entries(int n, bool pooled, int threads 
 // index read on the way to it), then the tables (dword aligned)
 __host__ __device__ inline size_t grid_lds_bytes(int n, bool pooled, int threads = PT_GRID_BLOCK_THREADS) {
   const size_t head = (size_t)n * sizeof(float4) + kGridBigGeomBytes + kGridMaxBig * sizeof(uint16_t);
-  if (pooled) return head + (size_t)(grid_max_entries(n, true, threads) + grid_prim_entries(threads)) * 8;
+  if (pooled) return head + (size_t)(grid_max_entries(n, true, threads) + grid_prim_entries(threads)) * 8 + (size_t)kGridEmisWords * 4;
   return head + (kGridCellsOff - kGridStartOff);
 }
 
@@ -129,6 +134,8 @@ struct GridLds {
   const uint16_t* cell_start;  // variants 11, 12
   const uint16_t* items;
   const uint2* cells;          // variant 13
+  const uint32_t* em_bits;     // variant 13: bit i set = sphere i emits (any emission component other than +-0)
+  const uint16_t* em_list;     // ... and the emitting spheres inside the grid (GridHeader::n_emis of them)
 };
 
 template <bool POOLED>
@@ -144,10 +151,17 @@ __device__ __forceinline__ GridLds stage_grid(const pt_sphere* __restrict__ sphe
   g.big = reinterpret_cast<const uint16_t*>(tab);
   const int ncells = (int)(g.h.nx * g.h.ny * g.h.nz);
   uint32_t* after_big = tab + kGridMaxBig / 2;
+  g.em_bits = nullptr;
+  g.em_list = nullptr;
+  uint32_t* em_lds = nullptr;
   if constexpr (POOLED) {
     g.cells = reinterpret_cast<const uint2*>(after_big);  // (8-byte aligned: everything before it is a multiple of 16 bytes)
     g.items = nullptr;  // not staged: the table's chained entries carry the long lists
     g.cell_start = nullptr;
+    // behind the cells and the per-lane primary lists (grid_lds_bytes): the emission bitmap and list
+    em_lds = after_big + 2 * (size_t)(grid_max_entries(n, true, (int)blockDim.x) + grid_prim_entries((int)blockDim.x));
+    g.em_bits = em_lds;
+    g.em_list = reinterpret_cast<const uint16_t*>(em_lds + PT_GRID_MAX_SPHERES / 32);
   } else {
     g.cell_start = reinterpret_cast<const uint16_t*>(after_big);
     g.items = g.cell_start + (kGridMaxCells + 2);
@@ -169,6 +183,8 @@ __device__ __forceinline__ GridLds stage_grid(const pt_sphere* __restrict__ sphe
     const int n_entries = (int)(g.h.n_big >> 16);
     const uint32_t* src_cells = accel + kGridCellsOff / 4;
     for (int i = threadIdx.x; i < 2 * n_entries; i += blockDim.x) after_big[i] = src_cells[i];
+    const uint32_t* src_em = accel + kGridEmisOff / 4;
+    for (int i = threadIdx.x; i < kGridEmisWords; i += blockDim.x) em_lds[i] = src_em[i];
   } else {
     const int words_i = ((int)g.h.n_items + 1) / 2;
     const uint32_t* src_items = accel + kGridItemsOff / 4;
@@ -203,7 +219,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
   __shared__ uint32_t scan_tmp[kGridBuildThreads];
   __shared__ int bb[6];
   __shared__ float fsum;
-  __shared__ uint32_t n_small, n_big, total, total_ext;
+  __shared__ uint32_t n_small, n_big, total, total_ext, s_n_emis;
   __shared__ float s_cs;
   __shared__ uint32_t s_dims[3];
   __shared__ float enc[6];
@@ -224,6 +240,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
   if (tid == 0) {
     fsum = 0.0f;
     n_small = n_big = total = 0u;
+    s_n_emis = 0u;
     bb[0] = bb[1] = bb[2] = 0x7FFFFFFF;
     bb[3] = bb[4] = bb[5] = (int)0x80000000;
   }
@@ -439,6 +456,29 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
           items[p] = (uint16_t)i;
         }
   }
+  // which spheres emit (grid_last_shortcut): bitmap over all spheres, list of the emitting ones inside the grid
+  {
+    uint32_t* em = accel + kGridEmisOff / 4;
+    uint16_t* em_list = reinterpret_cast<uint16_t*>(em + PT_GRID_MAX_SPHERES / 32);
+    for (int wd = tid; wd < PT_GRID_MAX_SPHERES / 32; wd += kGridBuildThreads) {
+      uint32_t bits = 0u;
+      for (int b = 0; b < 32; b++) {
+        const int i = 32 * wd + b;
+        if (i < n) {
+          const pt_sphere sp = spheres[i];
+          const uint32_t any = (__float_as_uint(sp.emission[0]) | __float_as_uint(sp.emission[1]) | __float_as_uint(sp.emission[2])) & 0x7FFFFFFFu;
+          if (any != 0u) {  // (a NaN or an infinity emits, too)
+            bits |= 1u << b;
+            if (in_grid(sp.radius)) {
+              const uint32_t p = atomicAdd(&s_n_emis, 1u);
+              if (p < (uint32_t)kGridMaxEmis) em_list[p] = (uint16_t)i;
+            }
+          }
+        }
+      }
+      em[wd] = bits;
+    }
+  }
   __threadfence();
   __syncthreads();
   // The cell table in the pooled walk's form (layout: head of this file).  Where a cell's chained entries start: exclusive scan
@@ -506,7 +546,7 @@ __global__ void __launch_bounds__(kGridBuildThreads) build_grid_kernel(const pt_
     h.r_small = r_small;
     h.r_big = r_big;
     h.prim_base = (uint32_t)max_entries;
-    h.pad_ = 0u;
+    h.n_emis = s_n_emis > (uint32_t)kGridMaxEmis ? 0xFFFFu : s_n_emis;
     *hdr = h;
   }
 }
@@ -985,6 +1025,9 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 #ifndef PT_V13_SKIP_SETUP
 #define PT_V13_SKIP_SETUP 1    // grid_begin: no clip / DDA set-up when no lane of the wave walks
 #endif
+#ifndef PT_V13_LAST_SHORTCUT
+#define PT_V13_LAST_SHORTCUT 1 // intersect_scene_grid_pooled: a path's last bounce walks only if it may end on an emitting sphere
+#endif
 #ifndef PT_V13_LAST_NOEXACT
 #define PT_V13_LAST_NOEXACT 1  // grid_end: a path's last bounce confirms its winner without the FP64 exact step
 #endif
@@ -1414,6 +1457,37 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
   // the allocator's split copies landed in front of the exec restore: EXACTNESS.md A.12.)
   grid_begin<true>(w, G, o, d, a, prim & walker, walker);
   const float INF = __builtin_inff();
+#if PT_V13_LAST_SHORTCUT
+  // THE LAST BOUNCE OF A PATH NEEDS THE WALK ONLY IF IT MAY END ON AN EMITTING SPHERE (round 5).  All that outlives such a bounce
+  // is `hit` (the colour-variance update of :200 against the bare `return` of :157-161) and `color += mask * emission` of the
+  // sphere hit (:174) -- and all but a handful of a scene's spheres emit +-0, for which that sum is `color` itself whichever of
+  // them is the nearest.  So: the spheres outside the grid have just been ranked (grid_begin); the emitting spheres inside it
+  // (GridHeader::n_emis <= 16 of them: BASELINE's 1000-sphere scene has 10) are ranked on top; and if the winner of THAT set
+  //   * is accepted by the reference for certain (grid_end's confirmations for `last`: a hit exists),
+  //   * does not emit, and
+  //   * leads every other ranked sphere -- every emitting one among them -- by more than the ranking's ambiguity margin,
+  // then the reference's nearest sphere is the winner or an unranked one, i.e. one that emits +-0 either way: same `hit`, same
+  // colour, same two draws -- and no walk.  Anything else (no sphere outside the grid hit: open scenes; an emitting winner; a
+  // near tie) walks as before.  Sets of up to 16: beyond, and in scenes without spheres outside the grid, nothing changes.
+  if (G.h.n_emis != 0xFFFFu && (G.h.n_big & 0xFFFFu) != 0u && __builtin_amdgcn_ballot_w64(last & walker) != 0ull) {
+    const float a4 = 4.0f * a, Tlim = 1000000.0f * (2.0f * a), Tlim_hi = Tlim * 1.0000153f;
+    if (last & walker) {
+      const int ne = (int)G.h.n_emis;  // wave-uniform
+      for (int k = 0; k < ne; k++) {
+        const int i = (int)G.em_list[k];
+        const float4 gi = G.geom[i];
+        if (near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);  // (a doubted test: the reference's own)
+      }
+      const uint32_t emits = (G.em_bits[(uint32_t)w.s.i1 >> 5] >> ((uint32_t)w.s.i1 & 31u)) & 1u;
+      const bool settled = (w.s.T1 < INF) & (emits == 0u) & (w.s.T2 > w.s.T1 * 1.0000038f) & (w.s.T1 < Tlim * 0.99998f);
+      if (settled) {
+        w.walking = false;
+        w.e0 = 0u;
+        w.e1 = 0u;
+      }
+    }
+  }
+#endif
   w.s.T1 = walker ? w.s.T1 : INF;
   w.s.T2 = walker ? w.s.T2 : INF;
   w.walking = w.walking & walker;

@@ -761,3 +761,48 @@ def test_wide_grid_kernel_on_large_scenes(pt, oracle, gpu):
     assert r.kernel_info(1500)["variant"] == 14 and r.kernel_info(1500)["block_threads"] == 1024
     assert r.kernel_info(1000)["variant"] == 13 and r.kernel_info(2049)["variant"] == 10
     r.destroy()
+
+
+@pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
+def test_last_bounce_shortcut_of_the_grid_kernel(pt, oracle, gpu, rng):
+    """Variants 13 / 14 skip the walk of a path's LAST bounce when the ranking of the spheres outside the grid plus the (<= 16) emitting
+    spheres inside it is won, clear of the ambiguity margin, by a sphere that does not emit (csrc/pt_grid.h, PT_V13_LAST_SHORTCUT;
+    EXACTNESS.md A.16).  Scenes built to sit on every branch of that rule: no / 12 / exactly 16 / 17 emitting grid spheres (17: rule
+    off), an emitting WALL, NaN and negative emission, emitting spheres packed around the camera so that last bounces often end on
+    them, no walls at all (nothing certifies a hit); 2..8 bounces; against the oracle, bit for bit."""
+    g = np.random.default_rng(1234 + rng)
+    w, h = 128, 64
+    basis = pt.camera_basis(width=w, height=h)
+    cases = []
+    for n_em, walls, wall_emits, special in ((0, True, False, None), (12, True, False, None), (16, True, True, None), (17, True, False, None),
+                                             (12, False, False, None), (10, True, False, "nan"), (14, True, False, "near")):
+        sc = pt.scene_random(600, seed=100 + n_em, with_walls=walls)
+        k0 = 7 if walls else 0
+        sc["emission"][k0:] = 0.0
+        pick = k0 + g.choice(len(sc) - k0, size=n_em, replace=False)
+        sc["emission"][pick] = g.uniform(0.5, 6.0, size=(n_em, 3)).astype(np.float32)
+        if wall_emits:
+            sc["emission"][1] = (0.3, 0.2, 0.1)
+        if special == "nan":
+            sc["emission"][pick[0]] = (np.nan, 1.0, 0.0)
+            sc["emission"][pick[1]] = (-2.0, 0.0, 0.0)
+            sc["emission"][pick[2]] = (0.0, -0.0, np.inf)
+        if special == "near":  # the emitting spheres in a shell around the default camera's view: many last bounces end on them
+            sc["pos"][pick] = (np.array([50.0, 45.0, 120.0]) + g.normal(0, 18.0, size=(n_em, 3))).astype(np.float32)
+            sc["radius"][pick] = g.uniform(2.5, 3.0, size=n_em).astype(np.float32)
+        cases.append((f"{n_em} emitting, walls={walls}, wall emits={wall_emits}, {special}", sc))
+    for name, sc in cases:
+        for mb, spp in ((5, 4), (2, 5), (8, 4), (3, 6)):
+            ref = oracle.render(w, h, spp, spheres=sc, basis=basis, rng_mode=rng, max_bounces=mb)
+            if "nan" in name:
+                # a NaN's sign and payload are the machine's (x86 and gfx950 produce different quiet NaNs from the same operation; the
+                # contract fixes values): which floats are NaN must agree with the oracle, everything else bit for bit -- and the grid
+                # kernels must agree with the brute-force kernel on the same machine in every bit
+                brute, _ = pt.render_frame(w, h, spp, spheres=sc, basis=basis, rng_mode=rng, max_bounces=mb, variant=10)
+                assert np.array_equal(np.isnan(brute), np.isnan(ref)) and np.isnan(ref).any()
+                ok = ~np.isnan(ref)
+                assert np.array_equal(brute.view(np.uint32)[ok], ref.view(np.uint32)[ok])
+                ref = brute
+            for v in (13, 14):
+                img, _ = pt.render_frame(w, h, spp, spheres=sc, basis=basis, rng_mode=rng, max_bounces=mb, variant=v)
+                assert_bit_exact(img, ref, f"{name}; {mb} bounces, {spp} spp, variant {v}")
