@@ -83,7 +83,7 @@ constexpr size_t kGridStartOff = kGridBigOff + kGridMaxBig * sizeof(uint16_t);
 constexpr size_t kGridItemsOff = kGridStartOff + (kGridMaxCells + 2) * sizeof(uint16_t);
 constexpr size_t kGridCellsOff = (kGridItemsOff + kGridMaxItems * sizeof(uint16_t) + 7) & ~(size_t)7;
 // Round 5 (grid_last_shortcut): which spheres EMIT -- a bitmap over all spheres and the list of the emitting spheres inside the grid
-constexpr int kGridMaxEmis = 16;                                  // more emitting grid spheres than this: the shortcut is off
+constexpr int kGridMaxEmis = 32;                                  // more emitting grid spheres than this: the shortcut is off
 constexpr int kGridEmisWords = PT_GRID_MAX_SPHERES / 32 + kGridMaxEmis / 2;  // bitmap, then the list (u16)
 constexpr size_t kGridEmisOff = kGridCellsOff + (size_t)(kGridMaxEntries + 1) * 2 * sizeof(uint32_t);
 constexpr size_t kGridAccelBytes = kGridEmisOff + (size_t)kGridEmisWords * sizeof(uint32_t);
@@ -1462,13 +1462,13 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
   // is `hit` (the colour-variance update of :200 against the bare `return` of :157-161) and `color += mask * emission` of the
   // sphere hit (:174) -- and all but a handful of a scene's spheres emit +-0, for which that sum is `color` itself whichever of
   // them is the nearest.  So: the spheres outside the grid have just been ranked (grid_begin); the emitting spheres inside it
-  // (GridHeader::n_emis <= 16 of them: BASELINE's 1000-sphere scene has 10) are ranked on top; and if the winner of THAT set
+  // (GridHeader::n_emis <= 32 of them: BASELINE's 1000-sphere scene has 10) are ranked on top; and if the winner of THAT set
   //   * is accepted by the reference for certain (grid_end's confirmations for `last`: a hit exists),
   //   * does not emit, and
   //   * leads every other ranked sphere -- every emitting one among them -- by more than the ranking's ambiguity margin,
   // then the reference's nearest sphere is the winner or an unranked one, i.e. one that emits +-0 either way: same `hit`, same
   // colour, same two draws -- and no walk.  Anything else (no sphere outside the grid hit: open scenes; an emitting winner; a
-  // near tie) walks as before.  Sets of up to 16: beyond, and in scenes without spheres outside the grid, nothing changes.
+  // near tie) walks as before.  Sets of up to 32: beyond, and in scenes without spheres outside the grid, nothing changes.
   if (G.h.n_emis != 0xFFFFu && (G.h.n_big & 0xFFFFu) != 0u && __builtin_amdgcn_ballot_w64(last & walker) != 0ull) {
     const float a4 = 4.0f * a, Tlim = 1000000.0f * (2.0f * a), Tlim_hi = Tlim * 1.0000153f;
     if (last & walker) {

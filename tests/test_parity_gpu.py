@@ -765,16 +765,16 @@ def test_wide_grid_kernel_on_large_scenes(pt, oracle, gpu):
 
 @pytest.mark.parametrize("rng", [0, 1], ids=["xorwow", "philox"])
 def test_last_bounce_shortcut_of_the_grid_kernel(pt, oracle, gpu, rng):
-    """Variants 13 / 14 skip the walk of a path's LAST bounce when the ranking of the spheres outside the grid plus the (<= 16) emitting
+    """Variants 13 / 14 skip the walk of a path's LAST bounce when the ranking of the spheres outside the grid plus the (<= 32) emitting
     spheres inside it is won, clear of the ambiguity margin, by a sphere that does not emit (csrc/pt_grid.h, PT_V13_LAST_SHORTCUT;
-    EXACTNESS.md A.16).  Scenes built to sit on every branch of that rule: no / 12 / exactly 16 / 17 emitting grid spheres (17: rule
+    EXACTNESS.md A.16).  Scenes built to sit on every branch of that rule: no / 12 / exactly 32 / 33 emitting grid spheres (33: rule
     off), an emitting WALL, NaN and negative emission, emitting spheres packed around the camera so that last bounces often end on
     them, no walls at all (nothing certifies a hit); 2..8 bounces; against the oracle, bit for bit."""
     g = np.random.default_rng(1234 + rng)
     w, h = 128, 64
     basis = pt.camera_basis(width=w, height=h)
     cases = []
-    for n_em, walls, wall_emits, special in ((0, True, False, None), (12, True, False, None), (16, True, True, None), (17, True, False, None),
+    for n_em, walls, wall_emits, special in ((0, True, False, None), (12, True, False, None), (32, True, True, None), (33, True, False, None),
                                              (12, False, False, None), (10, True, False, "nan"), (14, True, False, "near")):
         sc = pt.scene_random(600, seed=100 + n_em, with_walls=walls)
         k0 = 7 if walls else 0
