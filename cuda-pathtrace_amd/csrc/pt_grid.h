@@ -41,6 +41,13 @@ namespace pt {
 // six waves per SIMD, 3: 12.7 and 4: 13.0 at four (profiles/r03/cfg4_ab.txt); variant 11 is indifferent (16.6-16.7 ms).  With sample
 // chunking on (steady frame times, 256 spp, closed | open ms): 2: 95.5 | 35.3, 2.25: 96.0 | 35.1, 2.5: 94.4 | 35.3, 2.75: 94.3 | 35.4,
 // 3: 95.6 | 35.1, 3.5: 96.3 | 35.4 -- flat within a percent (the steps are the cell counts per axis changing): 2.75.
+#ifndef PT_V13_LAST_SHORTCUT
+#define PT_V13_LAST_SHORTCUT 1  // grid_begin: a path's last bounce walks only if it may end on an emitting sphere
+#endif
+// (Measured and dropped, round 5 -- profiles/r05/cfg4_ab.txt block 9: skipping the clip / DDA set-up when no lane of the wave walks, and
+// confirming a last bounce's winner from its float part instead of the FP64 step (EXACTNESS.md A.8's rule, in the grid's units): each
+// made the kernel 0.5-1 % SLOWER -- a branch and its live ranges cost more than the instructions they skip.  Both were first
+// measured as "no effect": their switches were defined BEHIND the code that tested them, so they were silently off.)
 #ifndef PT_GRID_MAX_CELLS
 #define PT_GRID_MAX_CELLS 4096
 #endif
@@ -682,10 +689,10 @@ struct GridWalk {
 // `prim` (variant 13, round 5): the ray is a PRIMARY ray of a pixel whose list of visible grid spheres was built before the sample
 // loop (pt_primlist.h).  Such a lane does not walk: the "cell" it starts in is its list (same entry format, links included) and
 // it is marked as having left the grid, so the pooled loop tests the list's spheres and nothing else.
-// `walks` false: a lane that is here only to help (variant 13).  When NO lane of the wave walks -- a closed scene's bounce 0, where
-// every lane is a primary ray with a list -- the clip against the box and the DDA set-up are skipped (wave-uniform branch).
+// `last` (variant 13, round 5): the ray is a path's last bounce -- it walks only if it may end on an emitting sphere (below).
 template <bool POOLED = false>
-__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a, bool prim = false, bool walks = true) {
+__device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, F3 d, float a, bool prim = false, bool walks = true,
+                                           bool last = false) {
   const float INF = __builtin_inff();
   const float two_a = 2.0f * a, a4 = 4.0f * a;
   const float Tlim = 1000000.0f * two_a;
@@ -715,6 +722,35 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
       }
     }
   }
+  bool settled = false;
+#if PT_V13_LAST_SHORTCUT
+  // THE LAST BOUNCE OF A PATH NEEDS THE WALK ONLY IF IT MAY END ON AN EMITTING SPHERE (round 5; EXACTNESS.md A.16).  All that
+  // outlives such a bounce is `hit` (the colour-variance update of :200 against the bare `return` of :157-161) and `color +=
+  // mask * emission` of the sphere hit (:174) -- and all but a handful of a scene's spheres emit +-0, for which that sum is
+  // `color` itself whichever of them is the nearest.  So: the spheres outside the grid have just been ranked; the emitting
+  // spheres inside it (GridHeader::n_emis <= 32 of them: BASELINE's 1000-sphere scene has 10) are ranked on top; and if the
+  // winner of THAT set
+  //   * is accepted by the reference for certain (grid_end's confirmations for `last`: a hit exists),
+  //   * does not emit, and
+  //   * leads every other ranked sphere -- every emitting one among them -- by more than the ranking's ambiguity margin,
+  // then the reference's nearest sphere is the winner or an unranked one, i.e. one that emits +-0 either way: same `hit`, same
+  // colour, same two draws -- and no walk.  Anything else (no sphere outside the grid hit: open scenes; an emitting winner; a
+  // near tie) walks as before.  Sets of up to 32: beyond, and in scenes without spheres outside the grid, nothing changes.
+  if constexpr (POOLED) {
+    if (G.h.n_emis != 0xFFFFu && (G.h.n_big & 0xFFFFu) != 0u && __builtin_amdgcn_ballot_w64(last) != 0ull) {
+      if (last) {
+        const int ne = (int)G.h.n_emis;  // wave-uniform
+        for (int k = 0; k < ne; k++) {
+          const int i = (int)G.em_list[k];
+          const float4 gi = G.geom[i];
+          if (near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);  // (a doubted test: the reference's own)
+        }
+        const uint32_t emits = (G.em_bits[(uint32_t)w.s.i1 >> 5] >> ((uint32_t)w.s.i1 & 31u)) & 1u;
+        settled = (w.s.T1 < INF) & (emits == 0u) & (w.s.T2 > w.s.T1 * 1.0000038f) & (w.s.T1 < Tlim * 0.99998f);
+      }
+    }
+  }
+#endif
   bool active = false;
   int cidx = 0;
   float t_out = INF;
@@ -722,11 +758,7 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   w.cs0 = 0, w.cs1 = 0, w.cs2 = 0;
   uint32_t left = 0x20080200u;
   const float slack_t = G.h.slack * __builtin_amdgcn_rsqf(a);
-  bool somebody_walks = true;
-#if PT_V13_SKIP_SETUP
-  if constexpr (POOLED) somebody_walks = __builtin_amdgcn_ballot_w64(walks & !prim) != 0ull;
-#endif
-  if (somebody_walks) {
+  {
   // clip against the grid box
   const float gmin[3] = {G.h.ox, G.h.oy, G.h.oz};
   const float dims_f[3] = {(float)G.h.nx, (float)G.h.ny, (float)G.h.nz};
@@ -777,6 +809,7 @@ __device__ __forceinline__ void grid_begin(GridWalk& w, const GridLds& G, F3 o, 
   w.k0 = 0u, w.k1 = 0u;
   if constexpr (POOLED) {
     const uint2 e = G.cells[prim ? G.h.prim_base + (uint32_t)kPrimEntriesPerLane * threadIdx.x : (uint32_t)cidx];
+    active = active & !settled;
     w.e0 = (active | prim) ? e.x : 0u;
     w.e1 = e.y;
     active = active & !prim;
@@ -906,11 +939,7 @@ __device__ __forceinline__ void grid_trips(GridWalk& walk, const GridLds& G, F3 
   walk.have_next = have_next, walk.walking = walking;
 }
 
-// `last` (variant 13's regeneration loop, round 5): the caller uses only the hit/miss decision and the index -- the last bounce of
-// a path: emission of the sphere hit, nothing else; t, the hit point and the next ray are dead.  The winner's FP64 exact step is
-// then replaced by its float part and the two certainty tests of intersect_scene_screened_keys' LAST (pt_intersect.h; EXACTNESS.md
-// A.8 "Last bounce"), in this file's units: estimates are of 2a t and b = 2 d.off, so dacc here is four times dacc there and
-// a4 c four times a c -- exact powers of two on both sides of every compare.  A winner that fails either test goes the usual way.
+// `last` (variant 13's regeneration loop, round 5): a path's last bounce (see grid_begin); the winner is confirmed as for any bounce.
 __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, const GridLds& G, int n, F3 o, F3 d,
                                          float& t_hit, int& idx, bool last = false) {
   const float INF = __builtin_inff();
@@ -922,18 +951,6 @@ __device__ __forceinline__ bool grid_end(const GridWalk& w, const SceneLds& sc, 
   const float4 gw = G.geom[s.i1];
   bool hit = has;
   idx = s.i1;
-#if PT_V13_LAST_NOEXACT
-  if (last) {
-    const F3 off = mk3(o.x - gw.x, o.y - gw.y, o.z - gw.z);
-    const float b = 2.0f * dot(d, off);
-    const float c = dot(off, off) - gw.w;
-    const float a4 = 4.0f * w.a;
-    const float a4c = a4 * c;
-    const float dacc = fmaf(-a4, c, b * b);
-    const bool certain = (dacc > fabsf(a4c) * 4.7683716e-07f) & (s.T1 >= (2.0f * w.a) * 1e-30f);
-    ambiguous = ambiguous | (has & !certain);
-  } else
-#endif
   {
     bool bad = false;
     const RayConst rc = make_ray_const(d);
@@ -1022,15 +1039,6 @@ __device__ __forceinline__ bool intersect_scene_v11(const SceneLds& sc, int n, F
 // Doubted tests (origin within rounding distance of a surface) are decided on the spot by the reference's own FP64
 // expression, by the lane that drew the entry, from the owner's ray: same operands, same bits.  Everything after the walk
 // (ambiguity rule, exact step on the winner, literal fallback) is grid_end, unchanged.
-#ifndef PT_V13_SKIP_SETUP
-#define PT_V13_SKIP_SETUP 1    // grid_begin: no clip / DDA set-up when no lane of the wave walks
-#endif
-#ifndef PT_V13_LAST_SHORTCUT
-#define PT_V13_LAST_SHORTCUT 1 // intersect_scene_grid_pooled: a path's last bounce walks only if it may end on an emitting sphere
-#endif
-#ifndef PT_V13_LAST_NOEXACT
-#define PT_V13_LAST_NOEXACT 1  // grid_end: a path's last bounce confirms its winner without the FP64 exact step
-#endif
 #ifndef PT_POOL_STEPS
 #define PT_POOL_STEPS 2
 #endif
@@ -1455,39 +1463,8 @@ __device__ __forceinline__ bool intersect_scene_grid_pooled(const SceneLds& sc, 
   // (no branch around grid_begin for the helpers: they run it on whatever ray they last had -- the wave executes it anyway -- and
   // their walk is then emptied with selects.  A divergent region that ends here, in front of the register-hungry walk, is where
   // the allocator's split copies landed in front of the exec restore: EXACTNESS.md A.12.)
-  grid_begin<true>(w, G, o, d, a, prim & walker, walker);
+  grid_begin<true>(w, G, o, d, a, prim & walker, walker, last & walker);
   const float INF = __builtin_inff();
-#if PT_V13_LAST_SHORTCUT
-  // THE LAST BOUNCE OF A PATH NEEDS THE WALK ONLY IF IT MAY END ON AN EMITTING SPHERE (round 5).  All that outlives such a bounce
-  // is `hit` (the colour-variance update of :200 against the bare `return` of :157-161) and `color += mask * emission` of the
-  // sphere hit (:174) -- and all but a handful of a scene's spheres emit +-0, for which that sum is `color` itself whichever of
-  // them is the nearest.  So: the spheres outside the grid have just been ranked (grid_begin); the emitting spheres inside it
-  // (GridHeader::n_emis <= 32 of them: BASELINE's 1000-sphere scene has 10) are ranked on top; and if the winner of THAT set
-  //   * is accepted by the reference for certain (grid_end's confirmations for `last`: a hit exists),
-  //   * does not emit, and
-  //   * leads every other ranked sphere -- every emitting one among them -- by more than the ranking's ambiguity margin,
-  // then the reference's nearest sphere is the winner or an unranked one, i.e. one that emits +-0 either way: same `hit`, same
-  // colour, same two draws -- and no walk.  Anything else (no sphere outside the grid hit: open scenes; an emitting winner; a
-  // near tie) walks as before.  Sets of up to 32: beyond, and in scenes without spheres outside the grid, nothing changes.
-  if (G.h.n_emis != 0xFFFFu && (G.h.n_big & 0xFFFFu) != 0u && __builtin_amdgcn_ballot_w64(last & walker) != 0ull) {
-    const float a4 = 4.0f * a, Tlim = 1000000.0f * (2.0f * a), Tlim_hi = Tlim * 1.0000153f;
-    if (last & walker) {
-      const int ne = (int)G.h.n_emis;  // wave-uniform
-      for (int k = 0; k < ne; k++) {
-        const int i = (int)G.em_list[k];
-        const float4 gi = G.geom[i];
-        if (near2_test<true>(w.s, gi, i, o, d, a4, Tlim_hi)) near2_exact(w.s, gi, i, o, d, a, Tlim_hi);  // (a doubted test: the reference's own)
-      }
-      const uint32_t emits = (G.em_bits[(uint32_t)w.s.i1 >> 5] >> ((uint32_t)w.s.i1 & 31u)) & 1u;
-      const bool settled = (w.s.T1 < INF) & (emits == 0u) & (w.s.T2 > w.s.T1 * 1.0000038f) & (w.s.T1 < Tlim * 0.99998f);
-      if (settled) {
-        w.walking = false;
-        w.e0 = 0u;
-        w.e1 = 0u;
-      }
-    }
-  }
-#endif
   w.s.T1 = walker ? w.s.T1 : INF;
   w.s.T2 = walker ? w.s.T2 : INF;
   w.walking = w.walking & walker;

@@ -98,7 +98,7 @@
 #define PT_V13_WELFORD_TABLE 1  // variant 13: the Welford updates share one count and take delta / n through the 1/n table like the reference-scene kernels
 #endif
 #ifndef PT_V13_DEAD_END
-#define PT_V13_DEAD_END 1  // variant 13: the last bounce of a path forms no next ray and skips the winner's FP64 step (pt_trace.h, pt_grid.h)
+#define PT_V13_DEAD_END 1  // variant 13: the last bounce of a path forms no next ray (pt_trace.h) and walks only if it may end on an emitting sphere (pt_grid.h)
 #endif
 #ifndef PT_POOL_MIN_WAVES
 // variant 13 (variant 11 with the sphere tests pooled across the wave, pt_grid.h) is issue-bound, not latency-bound like its

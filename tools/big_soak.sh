@@ -5,6 +5,7 @@ O=gpurun_out/big_soak; mkdir -p $O
 run() { local name=$1; shift; python3 "$@" > $O/$name.txt 2>&1; echo "== $* -> rc=$? $(tail -1 $O/$name.txt | cut -c1-360)" | tee -a $O/summary.txt; }
 rm -f $O/summary.txt
 run primlist tools/primlist_soak.py 5000 100000
+run lastbounce tools/lastbounce_soak.py 3000 0
 run many tools/many_soak.py 6000 200000
 run many_large tools/many_soak.py 600 300000 large
 run fuzz tools/fuzz_soak.py 5000 400000

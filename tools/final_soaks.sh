@@ -8,6 +8,7 @@ mkdir -p $O
 python3 -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "pytest -m gpu rc=$? $(tail -1 $O/pytest_gpu.txt)" | tee $O/summary.txt
 run() { local name=$1; shift; echo "== $*" >> $O/summary.txt; python3 "$@" > $O/$name.txt 2>&1; echo "rc=$? $(tail -1 $O/$name.txt | cut -c1-400)" | tee -a $O/summary.txt; }
 run primlist tools/primlist_soak.py 1500 5000
+run lastbounce tools/lastbounce_soak.py 600 50000
 run many tools/many_soak.py 1200 30000
 run many_large tools/many_soak.py 150 40000 large
 run fuzz tools/fuzz_soak.py 1500 100000
