@@ -3,7 +3,7 @@
 # sharing one device, now between distinct devices over xGMI -- and BASELINE.md section 4's table filled from it.
 #   1. tests/test_mgpu_gpu.py (the distinct-device RCCL gather, the band policy between devices) and the bench multi-rank tests;
 #   2. bench.py --gpus {1,2,4,8} for cfg2 and cfg3 -- and the 1000-sphere frames cfg4 / cfg4open, whose row tiles are uneven
-#      (predicted x2.5 / x2.2 at N = 8 from one-GPU tile times) -- with both engines (one process per GPU + torch.distributed/RCCL; one process,
+#      (predicted x2.4 / x2.2 at N = 8 from one-GPU tile times) -- with both engines (one process per GPU + torch.distributed/RCCL; one process,
 #      pt_mgpu_* with banded exchange), every gathered frame compared bit for bit with the 1-GPU frame;
 #   3. the table: kernel ms, ms per frame (pipelined), one frame's latency, exposed gather, Msamples/s, efficiency.
 # Nothing here touches a GPU in this shell: every step is a child process.  Usage: tools/first_multi_gpu.sh [outdir=gpurun_out/mgpu]
