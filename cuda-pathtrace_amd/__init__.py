@@ -140,6 +140,8 @@ LAB_ABI = {
                                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
                                             ctypes.POINTER(ctypes.c_uint32)]),
     "pt_debug_grid_header": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_debug_grid_image": (ctypes.c_int, [_vp, ctypes.c_int, _fp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_uint64)]),
     "pt_debug_policy_ms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "pt_debug_policy_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
 }
@@ -339,6 +341,46 @@ def grid_header(spheres):
     return {"valid": int(u[0]), "dims": (int(u[1]), int(u[2]), int(u[3])), "origin": (float(f[4]), float(f[5]), float(f[6])),
             "cell_size": float(f[7]), "slack": float(f[9]), "centre": (float(f[10]), float(f[11]), float(f[12])),
             "far2": float(f[13]), "n_big": int(u[14]) & 0xFFFF, "n_entries": int(u[14]) >> 16, "n_items": int(u[15])}
+
+
+def grid_image(spheres, eye=None, threads=512):
+    """Diagnostics: everything the grid builder writes for a scene (pt_debug_grid_image), decoded: the header fields, the spheres
+    outside the grid, per cell the registered spheres (from the cell starts + registration list) and per cell the spheres the
+    pooled walk's table lists (inline entries and chained ones followed)."""
+    d_scene, n = upload_scene(spheres)
+    lay = (ctypes.c_uint64 * 8)()
+    check(lib.pt_debug_grid_image(d_scene.ptr, n, None, threads, None, 0, lay))
+    raw = (ctypes.c_uint32 * (int(lay[0]) // 4))()
+    eye_c = (ctypes.c_float * 3)(*eye) if eye is not None else None
+    check(lib.pt_debug_grid_image(d_scene.ptr, n, eye_c, threads, raw, int(lay[0]), lay))
+    u = np.frombuffer(raw, dtype=np.uint32).copy()
+    f, b = u.view(np.float32), u.view(np.uint8)
+    hdr = {"valid": int(u[0]), "dims": (int(u[1]), int(u[2]), int(u[3])), "origin": (float(f[4]), float(f[5]), float(f[6])),
+           "cell_size": float(f[7]), "slack": float(f[9]), "centre": (float(f[10]), float(f[11]), float(f[12])), "far2": float(f[13]),
+           "n_big": int(u[14]) & 0xFFFF, "n_entries": int(u[14]) >> 16, "n_items": int(u[15]), "r_small": float(f[16]),
+           "r_big": float(f[17]), "max_entries": int(lay[7])}
+    if not hdr["valid"]:
+        return hdr
+    ncells = hdr["dims"][0] * hdr["dims"][1] * hdr["dims"][2]
+    u16 = lambda off, cnt: b[off:off + 2 * cnt].view(np.uint16).astype(np.int64)
+    hdr["big"] = u16(int(lay[1]), hdr["n_big"])
+    start = u16(int(lay[2]), ncells + 1)
+    items = u16(int(lay[3]), hdr["n_items"])
+    hdr["cells"] = [items[start[c]:start[c + 1]] for c in range(ncells)]
+    tab = b[int(lay[4]):int(lay[4]) + 8 * hdr["n_entries"]].view(np.uint32).reshape(-1, 2)
+    pooled = []
+    for c in range(ncells):
+        got, e = [], c
+        for _ in range(hdr["n_entries"] + 1):
+            w0, w1 = int(tab[e, 0]), int(tab[e, 1])
+            k, link = w0 >> 30, (w0 >> 16) & 0x1FFF
+            got += [w0 & 0xFFFF, w1 & 0xFFFF, w1 >> 16][:k]
+            if link == 0:
+                break
+            e = link
+        pooled.append(np.asarray(got, dtype=np.int64))
+    hdr["pooled"] = pooled
+    return hdr
 
 
 def upload_scene(spheres):

@@ -159,3 +159,23 @@ extern "C" int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, u
   PT_HIPD(e);
   return PT_OK;
 }
+
+// diagnostics: the whole accelerator image build_grid_kernel writes for a scene (header, out-of-grid list, cell starts, registrations,
+// the pooled walk's cell table, emission data) and the byte offsets of its parts -- tests/test_grid_builder_gpu.py checks the
+// registrations against the geometry in float64
+extern "C" int pt_debug_grid_image(const pt_sphere* d_spheres, int n_spheres, const float* eye, int threads, uint32_t* image_out,
+                                   size_t image_bytes, uint64_t layout_out[8]) {
+  if (!d_spheres || !layout_out || n_spheres < 1) return pt_fail(PT_EINVAL, "pt_debug_grid_image: bad arguments");
+  pt_kernel_grid_layout(n_spheres, threads, layout_out);
+  const size_t need = (size_t)layout_out[0];
+  if (!image_out) return PT_OK;  // (size query)
+  if (image_bytes < need) return pt_fail(PT_EINVAL, "pt_debug_grid_image: the image needs %zu bytes", need);
+  uint32_t* d = nullptr;
+  PT_HIPD(hipMalloc((void**)&d, need));
+  hipError_t e = hipMemset(d, 0, need);
+  if (e == hipSuccess) e = pt_launch_build_grid(d_spheres, n_spheres, d, eye, true, nullptr, threads);
+  if (e == hipSuccess) e = hipMemcpy(image_out, d, need, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PT_HIPD(e);
+  return PT_OK;
+}

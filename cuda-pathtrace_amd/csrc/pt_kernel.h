@@ -208,6 +208,7 @@ hipError_t pt_launch_frames_kernel(const FramesKernelArgs& fa, int rng_mode, hip
 hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel, const float* eye /* camera hint or NULL */,
                                 bool pooled /* for variant 13's LDS image (fewer cells at large n) */, hipStream_t stream,
                                 int threads = PT_GRID_BLOCK_THREADS /* workgroup size of the kernel that will stage the grid */);
+void pt_kernel_grid_layout(int n_spheres, int threads, uint64_t out[8]);  // image bytes, part offsets, table capacities (pt_kernel.hip)
 size_t pt_kernel_accel_bytes(void);  // device scratch a renderer must provide in PixelKernelArgs::accel for variant 11
 hipError_t pt_launch_setup_random(uint32_t* state, int width, int row_begin, uint32_t tile_pixels, uint64_t seed,
                                   hipStream_t stream);

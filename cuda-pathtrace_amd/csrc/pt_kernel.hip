@@ -91,7 +91,8 @@ __device__ __forceinline__ void chunk_publish(const PixelKernelArgs& a, uint32_t
 //    its registers.  What goes is the ramp and tail of fr_count launches, the per-launch staging and the state traffic.  (First
 //    built as one workgroup per (frame, block) with the state handed on through the sample chunks' flags: a workgroup that
 //    becomes resident while its predecessor still runs only waits, and the dispatcher cannot pass it over for one that is
-//    ready -- 0.1145 ms per frame against 0.097 as single launches; profiles/r05/cfg5_frames.txt.)
+//    ready -- 0.1145 ms per frame against 0.097 as single launches; profiles/r05/cfg5_frames.txt.  Also measured, no effect:
+//    scattering the pixel blocks over the workgroups, so that no CU holds four neighbouring blocks -- 0.0936 vs 0.0938.)
 //  * the counter-based generator is re-keyed per frame, so its frames are independent: one workgroup per (frame, pixel block),
 //    frame-major -- the next frame's workgroups fill the slots the current one's leave (and the fifth slot per CU a single
 //    1024-workgroup frame cannot use).
@@ -1091,6 +1092,18 @@ hipError_t pt_launch_build_grid(const pt_sphere* spheres, int n, uint32_t* accel
   hipLaunchKernelGGL(pt::build_grid_kernel, dim3(1), dim3(pt::kGridBuildThreads), 0, stream, spheres, n, accel, eye ? eye[0] : 0.0f,
                      eye ? eye[1] : 0.0f, eye ? eye[2] : 0.0f, eye ? 1 : 0, pt::grid_max_entries(n, pooled, threads));
   return hipGetLastError();
+}
+
+// where the parts of the builder's image lie (lab diagnostics: pt_debug_grid_image)
+void pt_kernel_grid_layout(int n_spheres, int threads, uint64_t out[8]) {
+  out[0] = pt::kGridAccelBytes;
+  out[1] = pt::kGridBigOff;
+  out[2] = pt::kGridStartOff;
+  out[3] = pt::kGridItemsOff;
+  out[4] = pt::kGridCellsOff;
+  out[5] = pt::kGridEmisOff;
+  out[6] = (uint64_t)pt::kGridMaxCells;
+  out[7] = (uint64_t)pt::grid_max_entries(n_spheres, true, threads);
 }
 
 // does a launch with these arguments chain a pixel's samples through several workgroups (sample chunking)?

@@ -47,6 +47,12 @@ int pt_debug_div_compare(uint32_t n_first, uint32_t n_count, uint32_t first_bits
 /* Diagnostics: builds the uniform grid of kernel variant 11 for a scene and returns its 64-byte header
  * {valid, nx, ny, nz, origin xyz, cell size, 1/cell size, slack, centre xyz, (2E)^2, n_big, n_items}. */
 int pt_debug_grid_header(const pt_sphere* d_spheres, int n_spheres, uint32_t header_out[16]);
+/* Diagnostics: the whole image the grid builder writes for a scene, as the many-sphere kernel with `threads`-wide workgroups (512
+ * or 1024) would get it; `eye` = camera hint or NULL.  layout_out = {image bytes, byte offsets of: out-of-grid list (u16), cell
+ * starts (u16, cells + 2), registrations (u16), pooled cell table (2 x u32 per entry), emission data; cells the starts have room
+ * for; entries the pooled table may have}.  image_out NULL: only the layout is returned. */
+int pt_debug_grid_image(const pt_sphere* d_spheres, int n_spheres, const float* eye, int threads, uint32_t* image_out,
+                        size_t image_bytes, uint64_t layout_out[8]);
 /* The automatic policy's cost model (csrc/pt_capi.hip, "which kernel for a small scene"): predicted kernel milliseconds of
  * variant 6, 8 or 9 on a tile of `waves_per_simd` one-lane waves per SIMD at `spp` samples and `bounces` bounces.  Host
  * arithmetic only (no device needed): tests/test_policy_model.py holds it against the measured sweeps under profiles/. */
