@@ -18,7 +18,9 @@
  * writing stand-ins for them is not allowed.  The restatement is therefore pinned only by
  *   (1) values recorded in SURVEY.md section 8(c) / 8(a) (tests/golden/survey_kats.json),
  *   (2) analytic known answers derived from include/Scene.h + include/Camera.h in float64,
- *   (3) published known-answer vectors of the third-party generators (Philox4x32-10).
+ *   (3) published known-answer vectors of the third-party generators (Philox4x32-10),
+ *   (4) a second restatement of the whole path in numpy (tests/numpy_restatement.py, written from the
+ *       reference's lines, no code shared with this file) that pto_render reproduces bit for bit.
  * Third-party arithmetic that is NOT in /root/reference and is restated here:
  *   - cuRAND XORWOW device API (CUDA 8.0; README.md:16): curand_init/curand/curand_uniform
  *   - CUDA samples helper_math.h (CUDA 8.0; Makefile:3): float3 ops, dot, cross, normalize,
