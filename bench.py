@@ -607,8 +607,8 @@ def main():
                         "f32+f64), so the HBM fraction is <<1% by construction.  traffic = everything the counters saw: the "
                         "output, the persistent generator state (24 B in + 24 B out per pixel) and, on frames of few long "
                         "workgroups, one sample-chunk hand-over (104 B written + read per pixel: scheduling traffic, DESIGN.md 3)"
-                        + ("; the many-sphere kernel (variants 13 / 14) adds seven hand-overs and 48 B of register spills per lane that are "
-                           "stored and reloaded every bounce -- most of its traffic (DESIGN.md 4)" if ki["variant"] in (13, 14) else ""),
+                        + ("; the many-sphere kernel (variants 13 / 14) adds three hand-overs (four sample chunks) and 48 B of register spills per lane that are "
+                           "stored and reloaded every sample -- most of its traffic (DESIGN.md 4)" if ki["variant"] in (13, 14) else ""),
             },
             "valu_roofline": valu,
             "profile_stale": stale,
