@@ -115,8 +115,8 @@ def test_hip_first_hit_channels_equal_the_numpy_restatement(pt, gpu, scene):
 
 
 @pytest.mark.gpu
-def test_hip_grid_kernels_first_hit_channels_equal_the_numpy_restatement(pt, gpu):
-    """The many-sphere kernels (uniform grid, pooled tests; 1024-thread workgroups) on BASELINE config 4's kind of scene."""
+def test_hip_grid_kernels_first_hit_channels_equal_the_numpy_restatement(pt, lab, gpu):
+    """The many-sphere kernels (uniform grid -- variant 11, lab library; pooled tests; 1024-thread workgroups) on BASELINE config 4's kind of scene."""
     size = 128
     basis = pt.camera_basis(width=size, height=size)
     for walls in (True, False):
@@ -124,5 +124,5 @@ def test_hip_grid_kernels_first_hit_channels_equal_the_numpy_restatement(pt, gpu
         want = first_hit_frame(size, size, spheres, basis)
         assert want[..., 6].max() > 0.0
         for variant in (None, 11, 13, 14):
-            img, _ = pt.render_frame(size, size, 1, spheres, basis, max_bounces=2, variant=variant)
+            img, _ = (lab if variant == 11 else pt).render_frame(size, size, 1, spheres, basis, max_bounces=2, variant=variant)
             _check(img, want, f"HIP random300 walls={walls} variant {variant}")

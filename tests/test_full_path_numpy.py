@@ -99,13 +99,13 @@ def test_hip_frames_equal_the_numpy_restatement(pt, oracle, gpu, scene, size, sp
 
 
 @pytest.mark.gpu
-def test_hip_grid_kernels_equal_the_numpy_restatement(pt, oracle, gpu):
-    """The many-sphere kernels (grid walk, pooled tests, per-pixel primary lists at spp >= 4, last-bounce shortcut)."""
+def test_hip_grid_kernels_equal_the_numpy_restatement(pt, lab, oracle, gpu):
+    """The many-sphere kernels (grid walk -- variant 11 lives in the lab library; pooled tests, per-pixel primary lists at spp >= 4, last-bounce shortcut)."""
     size = 64
     basis = pt.camera_basis(width=size, height=size)
     for walls in (True, False):
         spheres = pt.scene_random(150, seed=5, with_walls=walls)
         want = NR.render_frame(size, size, 4, spheres, basis, _sincos_of(oracle), max_bounces=5)
         for variant in (None, 11, 13, 14):
-            img, _ = pt.render_frame(size, size, 4, spheres, basis, max_bounces=5, variant=variant)
+            img, _ = (lab if variant == 11 else pt).render_frame(size, size, 4, spheres, basis, max_bounces=5, variant=variant)
             _check_all(img, want, f"HIP random150 walls={walls} variant {variant}")
