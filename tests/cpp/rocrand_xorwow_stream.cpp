@@ -1,6 +1,6 @@
 // Test infrastructure (CPU suite): drives rocRAND's XORWOW engine -- a third party's implementation of Marsaglia's xorwow, the
 // generator cuRAND calls XORWOW (src/pathtrace.cu:131,223-224,265 draw from it) -- from a state given on the command line, so
-// that tests/test_xorwow_rocrand.py can compare its stream and its matrix-power skip-ahead with the oracle's restatement.
+// that tests/test_generators_rocrand.py can compare its stream and its matrix-power skip-ahead with the oracle's restatement.
 // rocRAND's header is host-compilable (plain g++); its SEED SCRAMBLE uses other constants than cuRAND's
 // (/opt/rocm/include/rocrand/rocrand_xorwow.h:113-116), so only the recurrence, the Weyl step and Marsaglia's base state can be
 // cross-checked here, not curand_init's scramble.

@@ -82,3 +82,26 @@ def test_marsaglias_base_state_is_the_same_in_both_libraries(oracle, engine):
     first, theirs, _ = engine("seed", 0x2C7F967F, 0xA03697CB, 0, 4096)
     assert list(ours) == first == [6615241, 123456789, 362436069, 521288629, 88675123, 5783321]
     assert theirs == oracle_stream(oracle, ours, 4096)
+
+
+def test_philox_block_function_equals_rocrands_on_random_counters_and_keys(oracle, tmp_path):
+    """Philox4x32-10 (the counter-based generator of north_star; no line of the reference): beyond the published Random123 vectors
+    (tests/golden/philox_kats.json) the oracle's block function equals rocRAND's `ten_rounds` on 20 000 random (counter, key) pairs
+    and on the all-ones / all-zero / single-bit patterns."""
+    import numpy as np
+    if not os.path.exists("/opt/rocm/include/rocrand/rocrand_philox4x32_10.h"):
+        pytest.skip("rocRAND headers not installed")
+    exe = str(tmp_path / "rocrand_philox_block")
+    res = subprocess.run(["g++", "-O1", "-w", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
+                          os.path.join(ROOT, "tests", "cpp", "rocrand_philox_block.cpp")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    rs = np.random.RandomState(20261005)
+    cases = rs.randint(0, 2**32, size=(20000, 6), dtype=np.uint64).astype(np.uint32)
+    special = [[0] * 6, [0xFFFFFFFF] * 6] + [[(1 << b) if w == j else 0 for j in range(6)] for w in range(6) for b in (0, 15, 31)]
+    cases = np.concatenate([np.array(special, dtype=np.uint32), cases])
+    text = "\n".join(" ".join(str(int(v)) for v in row) for row in cases) + "\n"
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout
+    theirs = np.array([[int(v) for v in line.split()] for line in out.strip().split("\n")], dtype=np.uint32)
+    assert theirs.shape == (len(cases), 4)
+    ours = np.stack([oracle.philox(row[:4], row[4:6]) for row in cases])
+    assert np.array_equal(ours, theirs)
