@@ -1,4 +1,4 @@
-"""The multi-GPU path on CPU: world_size 2 and 3 (ragged tiles) over gloo.  Each rank renders
+"""The multi-GPU path on CPU: world_size 2, 3 (ragged tiles) and 8 (the driver's largest launch; ragged) over gloo.  Each rank renders
 its row block with the oracle standing in for the HIP kernel, the product's FrameGather
 assembles the frame on rank 0, and the result must equal a single-process full frame bit for
 bit (generators are keyed on the global pixel id, so tiling cannot change any pixel)."""
@@ -61,6 +61,24 @@ def test_row_tiled_frame_equals_single_process_frame(oracle, world, size, rng):
         p.join(timeout=60)
         assert p.exitcode == 0
     full = oracle.render(size, size, 2, rng_mode=rng)
+    assert np.array_equal(frame.view(np.uint32), full.view(np.uint32))
+
+
+def test_eight_ranks_ragged_frame_equals_single_process_frame(oracle):
+    """World size 8 -- the largest launch the driver makes (`bench.py --gpus 8`), never run on hardware -- with a frame height that does
+    not divide (36 rows -> 5,5,5,5,4,4,4,4): seven receives posted by the root straight into the frame, one send per peer."""
+    world, size = 8, 36
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, size, 2, 0, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = oracle.render(size, size, 2, rng_mode=0)
     assert np.array_equal(frame.view(np.uint32), full.view(np.uint32))
 
 
